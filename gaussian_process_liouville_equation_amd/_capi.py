@@ -1,0 +1,296 @@
+"""ctypes view of include/gple.h.
+
+`Api` binds one shared library that exports the gple.h entry points under a given prefix.  The product binds
+libgple_hip.so with prefix "gple_" (see __init__.py); the test-only CPU oracle exports the same interface under
+"oracle_" (without contexts or device pointers) and is bound by oracle/binding.py with this same class, so the
+parity tests drive both sides with identical code.
+"""
+import ctypes as C
+
+import numpy as np
+
+GPLE_OK = 0
+CALC_ERROR = 0x1
+CALC_AVERAGE = 0x2
+CALC_DERIVATIVE = 0x4
+IO_DEVICE = 0x100
+
+# gple_real_array / gple_complex_array
+R_KERNEL, R_INVERSE, R_INVLBL, R_INVLBL_DERIV, R_LABEL, R_INVERSE_DIAG = range(6)
+C_KERNEL, C_PSEUDO, C_UPPER_LEFT, C_LOWER_LEFT, C_INVLBL, C_INVLBL_DERIV, C_LABEL = range(7)
+
+_dp = C.POINTER(C.c_double)
+
+
+class RealFitScalars(C.Structure):
+    _fields_ = [
+        ("rescale_factor", C.c_double),
+        ("magnitude", C.c_double),
+        ("error", C.c_double),
+        ("population", C.c_double),
+        ("first_order_average", C.c_double * 2),
+        ("purity", C.c_double),
+        ("error_derivative", C.c_double * 4),
+        ("population_derivative", C.c_double * 4),
+        ("purity_derivative", C.c_double * 4),
+        ("info", C.c_int),
+    ]
+
+
+class ComplexFitScalars(C.Structure):
+    _fields_ = [
+        ("rescale_factor", C.c_double),
+        ("magnitude", C.c_double),
+        ("error", C.c_double),
+        ("purity", C.c_double),
+        ("error_derivative", C.c_double * 8),
+        ("purity_derivative", C.c_double * 8),
+        ("info", C.c_int),
+    ]
+
+
+class PredictScalars(C.Structure):
+    _fields_ = [("error", C.c_double), ("error_derivative", C.c_double * 8)]
+
+
+def scalars_to_dict(s):
+    out = {}
+    for name, _ in s._fields_:
+        v = getattr(s, name)
+        out[name] = np.array(list(v)) if hasattr(v, "__len__") else v
+    return out
+
+
+class GpleError(RuntimeError):
+    pass
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _points(X):
+    """(N,2) array of phase-space points -> contiguous interleaved [x0,p0,x1,p1,...] (stdafx.h:153)."""
+    X = _f64(X)
+    if X.ndim != 2 or X.shape[1] != 2:
+        raise ValueError("phase-space points must have shape (N, 2)")
+    return X
+
+
+def _cplx(y):
+    return np.ascontiguousarray(y, dtype=np.complex128)
+
+
+# every symbol include/gple.h declares (checked by tests/test_capi_symbols.py)
+GPLE_SYMBOLS = [
+    "ctx_create", "ctx_destroy", "ctx_synchronize", "status_string", "ctx_last_error",
+    "real_gram", "cutoff_factor",
+    "real_fit_create", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
+    "complex_fit_create", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
+    "complex_predict", "loose_function", "nlml", "nlml_predict",
+]
+
+
+class _Fit:
+    """Owns one fit handle of either backend (RAII, like the reference's value-semantic kernel objects)."""
+
+    def __init__(self, api, handle, kind, N, scalars):
+        self.api, self.handle, self.kind, self.N = api, handle, kind, N
+        self.scalars = scalars
+
+    def release(self):
+        if self.handle:
+            getattr(self.api.lib, f"{self.api.prefix}{self.kind}_fit_release")(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def get(self, which):
+        N = self.N
+        if self.kind == "real":
+            shape = {R_KERNEL: (N, N), R_INVERSE: (N, N), R_INVLBL: (N,), R_INVLBL_DERIV: (4, N), R_LABEL: (N,),
+                     R_INVERSE_DIAG: (N,)}[which]
+            buf = np.empty(int(np.prod(shape)), dtype=np.float64)
+            self.api._fit_get(self, which, buf)
+            # N x N matrices arrive column-major: viewed as a C-ordered numpy array that is the transpose
+            return buf.reshape(shape).T.copy() if which in (R_KERNEL, R_INVERSE) else buf.reshape(shape)
+        shape, cplx = {C_KERNEL: ((N, N), False), C_PSEUDO: ((N, N), True), C_UPPER_LEFT: ((N, N), True),
+                       C_LOWER_LEFT: ((N, N), True), C_INVLBL: ((N,), True), C_INVLBL_DERIV: ((8, N), True),
+                       C_LABEL: ((N,), True)}[which]
+        buf = np.empty(int(np.prod(shape)) * (2 if cplx else 1), dtype=np.float64)
+        self.api._fit_get(self, which, buf)
+        arr = buf.view(np.complex128) if cplx else buf
+        arr = arr.reshape(shape)
+        return arr.T.copy() if which in (C_KERNEL, C_PSEUDO, C_UPPER_LEFT, C_LOWER_LEFT) else arr
+
+
+class Api:
+    def __init__(self, lib, prefix, with_ctx, device=0, stream=None):
+        self.lib, self.prefix, self.with_ctx = lib, prefix, with_ctx
+        self.ctx = None
+        self._declare()
+        if with_ctx:
+            ctx = C.c_void_p()
+            self._check(lib.gple_ctx_create(int(device), C.c_void_p(stream), C.byref(ctx)))
+            self.ctx = ctx
+
+    # ---- plumbing --------------------------------------------------------------------------------------------
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def _declare(self):
+        ctx = [C.c_void_p] if self.with_ctx else []
+        fl = [C.c_uint] if self.with_ctx else []  # the oracle has no flags on gram/cutoff/get
+        sz, vp, ci = C.c_size_t, C.c_void_p, C.c_int
+        sig = {
+            "real_gram": ctx + [_dp, _dp, sz, _dp, sz, ci] + fl + [_dp, _dp],
+            "cutoff_factor": ctx + [_dp, ci, _dp, sz] + fl + [_dp],
+            "real_fit_create": ctx + [_dp, _dp, _dp, ci, sz, C.c_uint, C.POINTER(RealFitScalars), C.POINTER(vp)],
+            "real_fit_release": [vp],
+            "real_fit_get": [vp, ci] + fl + [_dp],
+            "real_predict": ctx + [vp, _dp, sz, C.c_uint, _dp, _dp, _dp, _dp, C.POINTER(PredictScalars)],
+            "complex_fit_create": ctx + [_dp, _dp, _dp, sz, C.c_uint, C.POINTER(ComplexFitScalars), C.POINTER(vp)],
+            "complex_fit_release": [vp],
+            "complex_fit_get": [vp, ci] + fl + [_dp],
+            "complex_predict": ctx + [vp, _dp, sz, C.c_uint, _dp, _dp, _dp, _dp, C.POINTER(PredictScalars)],
+            "loose_function": ctx + [_dp, sz, _dp, _dp, sz, _dp, _dp, sz, _dp, _dp],
+            "nlml": ctx + [_dp, _dp, _dp, sz, _dp, _dp],
+            "nlml_predict": ctx + [_dp, _dp, _dp, sz, _dp, sz] + fl + [_dp],
+        }
+        for name, argtypes in sig.items():
+            f = self._fn(name)
+            f.argtypes, f.restype = argtypes, C.c_int
+        if self.with_ctx:
+            self.lib.gple_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+            self.lib.gple_ctx_destroy.argtypes = [C.c_void_p]
+            self.lib.gple_ctx_synchronize.argtypes = [C.c_void_p]
+            self.lib.gple_status_string.argtypes, self.lib.gple_status_string.restype = [C.c_int], C.c_char_p
+            self.lib.gple_ctx_last_error.argtypes, self.lib.gple_ctx_last_error.restype = [C.c_void_p], C.c_char_p
+
+    def _check(self, status):
+        if status != GPLE_OK:
+            msg = f"status {status}"
+            if self.with_ctx:
+                msg = self.lib.gple_status_string(status).decode()
+                if self.ctx:
+                    msg += ": " + self.lib.gple_ctx_last_error(self.ctx).decode()
+            raise GpleError(msg)
+
+    def _c(self):
+        return [self.ctx] if self.with_ctx else []
+
+    def _fl(self, flags=0):
+        return [flags] if self.with_ctx else []
+
+    def close(self):
+        if self.ctx:
+            self.lib.gple_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def synchronize(self):
+        if self.ctx:
+            self._check(self.lib.gple_ctx_synchronize(self.ctx))
+
+    def _fit_get(self, fit, which, buf):
+        self._check(self._fn(f"{fit.kind}_fit_get")(fit.handle, which, *self._fl(), _ptr(buf)))
+
+    # ---- KernelBase ------------------------------------------------------------------------------------------
+    def real_gram(self, theta, left, right, same_features=False, derivative=False):
+        theta, left, right = _f64(theta), _points(left), _points(right)
+        R, Cc = len(left), len(right)
+        K = np.empty(R * Cc)
+        dK = np.empty(4 * R * Cc) if derivative else None
+        self._check(self._fn("real_gram")(*self._c(), _ptr(theta), _ptr(left), R, _ptr(right), Cc, int(same_features),
+                                          *self._fl(), _ptr(K), _ptr(dK)))
+        K = K.reshape(Cc, R).T  # column-major R x C
+        if derivative:
+            return K, dK.reshape(4, Cc, R).transpose(0, 2, 1)
+        return K
+
+    def cutoff_factor(self, prediction, variance):
+        is_c = np.iscomplexobj(prediction)
+        p = _cplx(prediction).view(np.float64) if is_c else _f64(prediction)
+        var = _f64(variance)
+        out = np.empty(len(var))
+        self._check(self._fn("cutoff_factor")(*self._c(), _ptr(p), int(is_c), _ptr(var), len(var), *self._fl(), _ptr(out)))
+        return out
+
+    # ---- TrainingKernel / PredictiveKernel -------------------------------------------------------------------
+    def real_fit(self, theta, X, y, flags):
+        theta, X = _f64(theta), _points(X)
+        is_c = np.iscomplexobj(y)
+        yy = _cplx(y).view(np.float64) if is_c else _f64(y)
+        sc, h = RealFitScalars(), C.c_void_p()
+        self._check(self._fn("real_fit_create")(*self._c(), _ptr(theta), _ptr(X), _ptr(yy), int(is_c), len(X), flags,
+                                                C.byref(sc), C.byref(h)))
+        return _Fit(self, h, "real", len(X), scalars_to_dict(sc))
+
+    def real_predict(self, fit, Xs, flags=0, labels=None, want=("prediction", "variance", "cutoff")):
+        Xs = _points(Xs)
+        M = len(Xs)
+        lab = None if labels is None else _f64(labels)
+        pred = np.empty(M) if "prediction" in want else None
+        var = np.empty(M) if "variance" in want else None
+        cut = np.empty(M) if "cutoff" in want else None
+        ps = PredictScalars()
+        self._check(self._fn("real_predict")(*self._c(), fit.handle, _ptr(Xs), M, flags, _ptr(lab), _ptr(pred), _ptr(var),
+                                             _ptr(cut), C.byref(ps)))
+        d = scalars_to_dict(ps)
+        d["error_derivative"] = d["error_derivative"][:4]
+        d.update(prediction=pred, variance=var, cutoff=cut)
+        return d
+
+    # ---- TrainingComplexKernel / PredictiveComplexKernel ------------------------------------------------------
+    def complex_fit(self, theta, X, y, flags):
+        theta, X, yy = _f64(theta), _points(X), _cplx(y).view(np.float64)
+        sc, h = ComplexFitScalars(), C.c_void_p()
+        self._check(self._fn("complex_fit_create")(*self._c(), _ptr(theta), _ptr(X), _ptr(yy), len(X), flags, C.byref(sc),
+                                                   C.byref(h)))
+        return _Fit(self, h, "complex", len(X), scalars_to_dict(sc))
+
+    def complex_predict(self, fit, Xs, flags=0, labels=None, want=("prediction", "variance", "cutoff")):
+        Xs = _points(Xs)
+        M = len(Xs)
+        lab = None if labels is None else _cplx(labels).view(np.float64)
+        pred = np.empty(2 * M) if "prediction" in want else None
+        var = np.empty(M) if "variance" in want else None
+        cut = np.empty(2 * M) if "cutoff" in want else None
+        ps = PredictScalars()
+        self._check(self._fn("complex_predict")(*self._c(), fit.handle, _ptr(Xs), M, flags, _ptr(lab), _ptr(pred),
+                                                _ptr(var), _ptr(cut), C.byref(ps)))
+        d = scalars_to_dict(ps)
+        d.update(prediction=None if pred is None else pred.view(np.complex128), variance=var,
+                 cutoff=None if cut is None else cut.view(np.complex128))
+        return d
+
+    # ---- objective / NLML ------------------------------------------------------------------------------------
+    def loose_function(self, x, X, y, X_extra, y_extra, want_grad=True):
+        x, X, Xe = _f64(x), _points(X), _points(X_extra)
+        yy, ye = _cplx(y).view(np.float64), _cplx(y_extra).view(np.float64)
+        val = C.c_double()
+        grad = np.empty(len(x)) if want_grad else None
+        self._check(self._fn("loose_function")(*self._c(), _ptr(x), len(x), _ptr(X), _ptr(yy), len(X), _ptr(Xe), _ptr(ye),
+                                               len(Xe), C.cast(C.byref(val), _dp), _ptr(grad)))
+        return val.value, grad
+
+    def nlml(self, x, X, y, want_grad=True):
+        x, X, y = _f64(x), _points(X), _f64(y)
+        val = C.c_double()
+        grad = np.empty(4) if want_grad else None
+        self._check(self._fn("nlml")(*self._c(), _ptr(x), _ptr(X), _ptr(y), len(X), C.cast(C.byref(val), _dp), _ptr(grad)))
+        return val.value, grad
+
+    def nlml_predict(self, x, X, y, Xs):
+        x, X, y, Xs = _f64(x), _points(X), _f64(y), _points(Xs)
+        out = np.empty(len(Xs))
+        self._check(self._fn("nlml_predict")(*self._c(), _ptr(x), _ptr(X), _ptr(y), len(X), _ptr(Xs), len(Xs), *self._fl(),
+                                             _ptr(out)))
+        return out

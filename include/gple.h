@@ -1,0 +1,178 @@
+/* gple.h — C-ABI of the MI355X-native GPR fit + predict hot path.
+ *
+ * Drop-in boundary for kaigu1997/gaussian_process_liouville_equation (reference paths are relative to
+ * /root/reference/gaussian_process_liouville_equation/ unless they start with test/).
+ * The reference has NO FFI of its own: its boundary is the C++ classes of kernel.h / complex_kernel.h /
+ * predict.h / opt.h.  Every entry point below names the reference constructor / getter it replaces; the
+ * header-only C++ adapters in gaussian_process_liouville_equation_amd/host/ re-create those classes on top
+ * of this ABI.
+ *
+ * Conventions
+ *   - all arithmetic is fp64; complex numbers are interleaved (re, im) pairs of doubles;
+ *   - phase-space points are 2 x N column-major == interleaved [x0,p0,x1,p1,...]   (stdafx.h:153);
+ *   - matrices returned by the *_get calls are column-major (Eigen default)          (stdafx.h:133);
+ *   - every function returns GPLE_OK (0) or a GPLE_ERR_* code; numerical breakdown is NOT an error:
+ *     like the reference (opt.cpp:420-431, LDLT::info() never checked) non-finite values are returned
+ *     in the outputs and `info` is set;
+ *   - array arguments are host pointers unless GPLE_IO_DEVICE is set in `flags`, in which case every
+ *     array argument of that call (inputs and outputs) is a device pointer on the context's device and
+ *     the call is asynchronous on the context's stream except for the scalar result block;
+ *   - predict calls are thread-safe on a shared const fit handle (evolve.cpp:392-420 calls the reference
+ *     predictors from TBB workers); fit calls on one context must not run concurrently.
+ */
+#ifndef GPLE_H
+#define GPLE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPLE_OK 0
+#define GPLE_ERR_BAD_ARG 1
+#define GPLE_ERR_HIP 2
+#define GPLE_ERR_ALLOC 3
+#define GPLE_ERR_STATE 4 /* e.g. derivative output requested from a fit built without GPLE_CALC_DERIVATIVE */
+
+/* The three bools of the Training*Kernel constructors (kernel.h:128-134, complex_kernel.h:167-173). */
+#define GPLE_CALC_ERROR 0x1u
+#define GPLE_CALC_AVERAGE 0x2u
+#define GPLE_CALC_DERIVATIVE 0x4u
+/* Array arguments of this call are device pointers. */
+#define GPLE_IO_DEVICE 0x100u
+
+#define GPLE_REAL_NPARAM 4    /* KernelBase::NumTotalParameters        kernel.h:33          */
+#define GPLE_COMPLEX_NPARAM 8 /* ComplexKernelBase::NumTotalParameters complex_kernel.h:22  */
+
+typedef struct gple_ctx gple_ctx;
+typedef struct gple_real_fit gple_real_fit;       /* TrainingKernel        kernel.h:111-280        */
+typedef struct gple_complex_fit gple_complex_fit; /* TrainingComplexKernel complex_kernel.h:150-318 */
+
+/* Scalar getters of TrainingKernel. Fields whose flag was not requested are NaN. */
+typedef struct gple_real_fit_scalars {
+	double rescale_factor;           /* get_rescale_factor            kernel.h:146, kernel.cpp:279 */
+	double magnitude;                /* get_magnitude                 kernel.h:167-179             */
+	double error;                    /* get_error (LOOCV)             kernel.cpp:285               */
+	double population;               /* get_population                kernel.cpp:286-297           */
+	double first_order_average[2];   /* get_1st_order_average         kernel.cpp:298-312           */
+	double purity;                   /* get_purity                    kernel.cpp:325-335           */
+	double error_derivative[4];      /* get_error_derivative          kernel.cpp:381-400           */
+	double population_derivative[4]; /* get_population_derivative     kernel.cpp:401-435           */
+	double purity_derivative[4];     /* get_purity_derivative         kernel.cpp:436-477           */
+	int info;                        /* 0: factorisation fine; k>0: non-positive pivot met at column k */
+} gple_real_fit_scalars;
+
+/* Scalar getters of TrainingComplexKernel. */
+typedef struct gple_complex_fit_scalars {
+	double rescale_factor;       /* complex_kernel.cpp:262       */
+	double magnitude;            /* complex_kernel.h:192-204     */
+	double error;                /* complex_kernel.cpp:270-286   */
+	double purity;               /* complex_kernel.cpp:357-377   */
+	double error_derivative[8];  /* complex_kernel.cpp:444-474   */
+	double purity_derivative[8]; /* complex_kernel.cpp:475-590   */
+	int info;
+} gple_complex_fit_scalars;
+
+/* Scalar getters of PredictiveKernel / PredictiveComplexKernel (only the first 4 entries of
+ * error_derivative are meaningful for the real kernel). NaN when no labels / no derivative were asked. */
+typedef struct gple_predict_scalars {
+	double error;               /* kernel.cpp:522, complex_kernel.cpp:646         */
+	double error_derivative[8]; /* kernel.cpp:524-542, complex_kernel.cpp:648-668 */
+} gple_predict_scalars;
+
+/* Arrays that the reference exposes through matrix/vector getters. */
+typedef enum gple_real_array {
+	GPLE_R_KERNEL = 0,       /* KernelBase::get_kernel,  N*N                kernel.h:82   */
+	GPLE_R_INVERSE = 1,      /* get_inverse,             N*N                kernel.h:153  */
+	GPLE_R_INVLBL = 2,       /* get_inverse_times_label, N                  kernel.h:160  */
+	GPLE_R_INVLBL_DERIV = 3, /* get_inverse_times_label_derivative, 4*N     kernel.h:215  */
+	GPLE_R_LABEL = 4,        /* rescaled label, N                           kernel.cpp:280 */
+	GPLE_R_INVERSE_DIAG = 5  /* diagonal of get_inverse, N                                */
+} gple_real_array;
+
+typedef enum gple_complex_array {
+	GPLE_C_KERNEL = 0,  /* get_kernel, N*N real                                 complex_kernel.h:90  */
+	GPLE_C_PSEUDO = 1,  /* get_pseudo_kernel, N*N complex                       complex_kernel.h:97  */
+	GPLE_C_UPPER_LEFT = 2,  /* get_upper_left_block_of_augmented_inverse, N*N complex   :208 */
+	GPLE_C_LOWER_LEFT = 3,  /* get_lower_left_block_of_augmented_inverse, N*N complex   :215 */
+	GPLE_C_INVLBL = 4,      /* get_upper_part_of_augmented_inverse_times_label, N complex :222 */
+	GPLE_C_INVLBL_DERIV = 5,/* ..._derivative, 8*N complex                               :245 */
+	GPLE_C_LABEL = 6        /* rescaled label, N complex                    complex_kernel.cpp:263 */
+} gple_complex_array;
+
+/* ---- context ------------------------------------------------------------------------------------- */
+/* device: HIP device ordinal; stream: a hipStream_t to run on, or NULL for a stream owned by the context. */
+int gple_ctx_create(int device, void* stream, gple_ctx** out);
+int gple_ctx_destroy(gple_ctx* ctx);
+int gple_ctx_synchronize(gple_ctx* ctx);
+const char* gple_status_string(int status);
+/* Last HIP error text seen by this context (empty string when none). */
+const char* gple_ctx_last_error(const gple_ctx* ctx);
+
+/* ---- KernelBase (kernel.h:29-106, kernel.cpp:8-242) ---------------------------------------------- */
+/* K = sf^2 (G + sn^2 delta) for theta = (sf, lx, lp, sn), left 2 x R, right 2 x C, K is R x C column-major.
+ * same_features != 0 reproduces the `LeftFeature.data() == RightFeature.data()` branch (identity delta,
+ * symmetric derivative with zero diagonal); dK (nullable) receives the 4 derivative matrices, 4*R*C. */
+int gple_real_gram(gple_ctx* ctx, const double theta[4], const double* left, size_t R, const double* right, size_t C,
+	int same_features, unsigned flags, double* K, double* dK);
+
+/* cutoff_factor<T> (kernel.h:301-332). prediction has M (real) or 2M (complex) doubles. */
+int gple_cutoff_factor(gple_ctx* ctx, const double* prediction, int is_complex, const double* variance, size_t M,
+	unsigned flags, double* factor);
+
+/* ---- TrainingKernel (kernel.cpp:244-479) ---------------------------------------------------------- */
+/* theta = (sf, lx, lp, sn); X = 2N; y: N labels; y_is_complex != 0 means y holds N (re,im) pairs of which
+ * the real part is used (ElementTrainingSet = tuple<PhasePoints, VectorXcd>, kernel.h:14, kernel.cpp:280). */
+int gple_real_fit_create(gple_ctx* ctx, const double theta[4], const double* X, const double* y, int y_is_complex,
+	size_t N, unsigned flags, gple_real_fit_scalars* scalars, gple_real_fit** out);
+int gple_real_fit_retain(gple_real_fit* fit);
+int gple_real_fit_release(gple_real_fit* fit);
+size_t gple_real_fit_size(const gple_real_fit* fit);
+/* Copies one array into dst (host pointer, or device pointer with GPLE_IO_DEVICE). Matrices that the hot
+ * path does not need (the explicit inverse) are materialised on first request. */
+int gple_real_fit_get(gple_real_fit* fit, gple_real_array which, unsigned flags, double* dst);
+
+/* ---- PredictiveKernel (kernel.cpp:481-544) -------------------------------------------------------- */
+/* Xs = 2M test points. labels (nullable, M) switches on `error`; GPLE_CALC_DERIVATIVE + labels switches on
+ * error_derivative (needs a fit created with GPLE_CALC_DERIVATIVE). prediction (nullable) receives the
+ * rescaled mean `Prediction`; variance / cutoff_prediction (nullable) as get_variance / get_cutoff_prediction. */
+int gple_real_predict(gple_ctx* ctx, const gple_real_fit* fit, const double* Xs, size_t M, unsigned flags,
+	const double* labels, double* prediction, double* variance, double* cutoff_prediction,
+	gple_predict_scalars* scalars);
+
+/* ---- TrainingComplexKernel / PredictiveComplexKernel (complex_kernel.cpp:221-670) ------------------ */
+/* theta = (s, sR, lRx, lRp, sI, lIx, lIp, sn); y = N (re,im) pairs. */
+int gple_complex_fit_create(gple_ctx* ctx, const double theta[8], const double* X, const double* y, size_t N,
+	unsigned flags, gple_complex_fit_scalars* scalars, gple_complex_fit** out);
+int gple_complex_fit_retain(gple_complex_fit* fit);
+int gple_complex_fit_release(gple_complex_fit* fit);
+size_t gple_complex_fit_size(const gple_complex_fit* fit);
+int gple_complex_fit_get(gple_complex_fit* fit, gple_complex_array which, unsigned flags, double* dst);
+/* labels: M (re,im) pairs or NULL; prediction / cutoff_prediction: M (re,im) pairs; variance: M. */
+int gple_complex_predict(gple_ctx* ctx, const gple_complex_fit* fit, const double* Xs, size_t M, unsigned flags,
+	const double* labels, double* prediction, double* variance, double* cutoff_prediction,
+	gple_predict_scalars* scalars);
+
+/* ---- loose_function (opt.cpp:441-482) -------------------------------------------------------------- */
+/* Objective of the NLopt drivers: LOOCV error of the training set + squared error on the extra set, and
+ * (grad != NULL) its gradient; n = 4 -> real kernel, n = 8 -> complex kernel. Labels are (re,im) pairs in
+ * both cases (the real kernel takes the real part, opt.cpp:451). make_normal (opt.cpp:420-431) is applied. */
+int gple_loose_function(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N,
+	const double* X_extra, const double* y_extra, size_t M_extra, double* value, double* grad);
+
+/* ---- negative_log_marginal_likelihood / predict (test/gpr.cpp:499-532, 654-706) -------------------- */
+/* Kernel = w_d^2 * Diag + w_g^2 * GaussianARD(weights), x = (w_d, w_g, a_x, a_p) with `a` the diagonal ARD
+ * weights = inverse lengths (NOCROSS build, test/gpr.cpp:99,323-326). value = y^T K^-1 y / 2 + sum log L_ii;
+ * grad (nullable, 4) = tr[(K^-1 - b b^T) dK] / 2 with the reference's dK (test/gpr.cpp:408-468). */
+int gple_nlml(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, double* value,
+	double* grad);
+/* Mean-only prediction k(x*, X) K^-1 y with the noise kernel excluded off the training set
+ * (test/gpr.cpp:384-388, 692-700). */
+int gple_nlml_predict(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, const double* Xs,
+	size_t M, unsigned flags, double* mean);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPLE_H */
