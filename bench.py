@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — GP fit + predict step (BASELINE.json metric) on 1..8 MI355X.
+
+One step = what the reference does per output tick for one density-matrix element:
+  TrainingKernel(theta, set, error=1, average=1, derivative=0)      (predict.cpp:390-393)
++ PredictiveKernel(grid, kernel, false): mean, variance, cut-off    (output.cpp:204-207)
+Workload C2 (BASELINE.json configs[1]): N = 1024 samples, 256 x 256 grid, real SE kernel, fp64, synthetic inputs of
+SURVEY.md §8(d) (seed 20240607 + 1).  Inputs are resident in HBM before the timed region.
+N > 1 GPUs: strong scaling of the same step — every rank fits (replicated, no broadcast needed) and predicts its
+contiguous slice of the grid; the slices are all-gathered over RCCL (the north-star partition).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {  # name: (N, G)
+    "C1": (256, 128),
+    "C2": (1024, 256),
+    "C4r": (4096, 512),  # one real element of C4 (north-star target size)
+}
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak; measured 78.4 with v_mfma_f64_16x16x4_f64
+
+
+def synthetic(N, G, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x0, p0, sx, sp = -10.0, 14.112, 0.7086, 0.7056
+    X = rng.normal([x0, p0], [sx, sp], size=(N, 2))
+    y = np.exp(-0.5 * (((X[:, 0] - x0) / sx) ** 2 + ((X[:, 1] - p0) / sp) ** 2)) / (2 * np.pi * sx * sp)
+    dx = 40.0 / G
+    xs = -20.0 + dx * np.arange(G)
+    ps = (p0 - np.pi / (2 * dx)) + (np.pi / dx / G) * np.arange(G)
+    gx, gp = np.meshgrid(xs, ps, indexing="ij")  # point index = ix * G + ip (input.cpp:37-70)
+    grid = np.ascontiguousarray(np.stack([gx.ravel(), gp.ravel()], axis=1))
+    return X, y, grid, np.array([1.0, sx, sp, 1e-2])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import gaussian_process_liouville_equation_amd as pkg
+    from gaussian_process_liouville_equation_amd import _capi as c
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    N, G = WORKLOADS[args.workload]
+    M = G * G
+    X, y, grid, theta = synthetic(N, G, 20240607 + 1)
+    # contiguous grid slice of this rank (padded to equal length so that all_gather_into_tensor applies)
+    per = (M + world - 1) // world
+    lo, hi = min(M, rank * per), min(M, (rank + 1) * per)
+
+    stream = torch.cuda.current_stream()
+    api = pkg.open_api(local_rank, stream=stream.cuda_stream)  # the library runs on torch's current stream
+    api.enable_timing(True)
+    dX = torch.from_numpy(X).cuda()
+    dy = torch.from_numpy(y).cuda()
+    dgrid = torch.from_numpy(grid[lo:hi].copy()).cuda()
+    out_local = torch.zeros(3, per, dtype=torch.float64, device="cuda")
+    out_full = torch.zeros(world, 3, per, dtype=torch.float64, device="cuda") if world > 1 else None
+    dp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))
+    th = np.ascontiguousarray(theta)
+    sc, ps = c.RealFitScalars(), c.PredictScalars()
+    flags = c.CALC_ERROR | c.CALC_AVERAGE | c.IO_DEVICE
+
+    def step():
+        h = C.c_void_p()
+        st = api.lib.gple_real_fit_create(api.ctx, th.ctypes.data_as(C.POINTER(C.c_double)), dp(dX), dp(dy), 0, N, flags, C.byref(sc), C.byref(h))
+        if st != 0:
+            raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
+        st = api.lib.gple_real_predict(api.ctx, h, dp(dgrid), hi - lo, c.IO_DEVICE, None, dp(out_local[0]), dp(out_local[1]), dp(out_local[2]), C.byref(ps))
+        if st != 0:
+            raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
+        if world > 1:
+            dist.all_gather_into_tensor(out_full, out_local)
+        api.lib.gple_real_fit_release(h)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    api.enable_timing(True)  # reset the accumulators
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    _, fit_total, fit_cnt = api.timing(0)
+    _, pk_total, pk_cnt = api.timing(2)
+    pk_ms = pk_total / max(1, pk_cnt)
+    m_local = hi - lo
+    # algorithmic flops of the dominant kernel: triangular contraction ||T k*||^2, N(N+1) flops per test point
+    # (the reference's row * K^-1 * row^T form would be 2 N^2)
+    flops = float(m_local) * N * (N + 1)
+    achieved = flops / (pk_ms * 1e-3) / 1e12 if pk_ms > 0 else 0.0
+    result = {
+        "metric": "GP fit+predict ms/step (N samples, M grid pts)",
+        "value": round(ms_per_step, 4),
+        "unit": "ms/step",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": False,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: N={N} samples, {G}x{G} grid (M={M}), real SE kernel, fit(error+average) + grid predict(mean,var,cutoff)",
+                   "N": N, "M": M, "parallelism": f"grid-sharded x{world}, replicated fit, RCCL all-gather" if world > 1 else "single GPU"},
+        "roofline": {"bound": "mfma", "kernel": "predict_q_kernel (fused K* generation + fp64 MFMA triangular contraction)",
+                     "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
+                     "traffic": None, "kernel_ms": round(pk_ms, 4), "algorithmic_flops_per_launch": flops,
+                     "reference_form_flops_per_launch": 2.0 * m_local * N * N},
+        "phases_ms": {"fit_device": round(fit_total / max(1, fit_cnt), 4), "predict_kernel": round(pk_ms, 4)},
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        from oracle import binding
+        ora = binding.load()
+        t0 = time.perf_counter()
+        fo = ora.real_fit(theta, X, y, 3)
+        tf = time.perf_counter() - t0
+        # bounded sample: the full fit + a slice of the grid, extrapolated linearly in M (rows are independent)
+        m_s = min(M, 16384)
+        t0 = time.perf_counter()
+        ora.real_predict(fo, grid[:m_s])
+        tp = (time.perf_counter() - t0) * (M / m_s)
+        result["cpu_baseline"] = {"value": round(1e3 * (tf + tp), 1), "unit": "ms/step", "cores": ora.num_threads, "kind": "port",
+                                  "sample": f"oracle (CPU restatement, OpenMP): full fit N={N} ({tf:.2f} s) + predict on {m_s} of {M} grid points scaled to M ({tp:.2f} s)"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    api.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,7 @@ libgple_hip.so with prefix "gple_" (see __init__.py); the test-only CPU oracle e
 parity tests drive both sides with identical code.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -87,7 +88,7 @@ def _cplx(y):
 
 # every symbol include/gple.h declares (checked by tests/test_capi_symbols.py)
 GPLE_SYMBOLS = [
-    "ctx_create", "ctx_destroy", "ctx_synchronize", "status_string", "ctx_last_error",
+    "ctx_create", "ctx_destroy", "ctx_synchronize", "status_string", "ctx_last_error", "ctx_enable_timing", "ctx_get_timing",
     "real_gram", "cutoff_factor",
     "real_fit_create", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
@@ -101,6 +102,7 @@ class _Fit:
     def __init__(self, api, handle, kind, N, scalars):
         self.api, self.handle, self.kind, self.N = api, handle, kind, N
         self.scalars = scalars
+        api._fits.add(self)
 
     def release(self):
         if self.handle:
@@ -136,6 +138,7 @@ class Api:
     def __init__(self, lib, prefix, with_ctx, device=0, stream=None):
         self.lib, self.prefix, self.with_ctx = lib, prefix, with_ctx
         self.ctx = None
+        self._fits = weakref.WeakSet()  # a context must outlive its fit handles: close() releases them first
         self._declare()
         if with_ctx:
             ctx = C.c_void_p()
@@ -191,9 +194,23 @@ class Api:
         return [flags] if self.with_ctx else []
 
     def close(self):
+        for f in list(self._fits):
+            f.release()
         if self.ctx:
             self.lib.gple_ctx_destroy(self.ctx)
             self.ctx = None
+
+    def enable_timing(self, on=True):
+        self.lib.gple_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.gple_ctx_enable_timing(self.ctx, int(on)))
+
+    def timing(self, which):
+        """(last_ms, total_ms, count) of timer 0 = fit, 1 = predict call, 2 = fused predict kernel."""
+        last, total, count = C.c_double(), C.c_double(), C.c_long()
+        self.lib.gple_ctx_get_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                 C.POINTER(C.c_long)]
+        self._check(self.lib.gple_ctx_get_timing(self.ctx, which, C.byref(last), C.byref(total), C.byref(count)))
+        return last.value, total.value, count.value
 
     def synchronize(self):
         if self.ctx:

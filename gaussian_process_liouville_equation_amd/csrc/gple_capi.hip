@@ -1,0 +1,895 @@
+// gple_capi.hip — C-ABI entry points of include/gple.h (host orchestration of the HIP kernels).
+//
+// Data layout in HBM (all fp64):
+//   training points  Xt   : 2 x Np interleaved, Np = round_up(N, 256), zero padded
+//   typed labels     ys   : n_total   (real GP: Np;  complex GP: [s Re y ; s Im y], 2 Np)
+//   inverse factor   T    : n_total x n_total column-major, T = chol(K_pad)^-1 (lower), upper part zero
+//   weights          v    : n_total   (K^-1 ys),  diag(K^-1) w : n_total,  complex: diag of the off-diagonal block wx : Np
+//   explicit inverse W    : n_total x n_total, built only for get_inverse()/derivatives (W = T^T T)
+// A fit handle owns Xt, ys, T, v, w (+ lazily W and the derivative vectors); the Cholesky work matrix, the merge-tree
+// workspace and all predict scratch belong to the context's buffer pool and are reused across calls.
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "gple_kernels.h"
+
+using namespace gple;
+
+namespace gple
+{
+	int record_hip_error(Ctx* ctx, hipError_t e, const char* what, int line)
+	{
+		if (ctx)
+		{
+			std::lock_guard<std::mutex> lk(ctx->mu);
+			ctx->last_error = std::string(hipGetErrorString(e)) + " in " + what + " (gple_capi.hip:" + std::to_string(line) + ")";
+		}
+		(void)hipGetLastError();
+		return e == hipErrorOutOfMemory ? GPLE_ERR_ALLOC : GPLE_ERR_HIP;
+	}
+	void timer_start(Ctx* c, int which)
+	{
+		if (c->timing) (void)hipEventRecord(c->ev[2 * which], c->stream);
+	}
+	void timer_stop(Ctx* c, int which)
+	{
+		if (c->timing)
+		{
+			(void)hipEventRecord(c->ev[2 * which + 1], c->stream);
+			c->ev_pending[which] = true;
+		}
+	}
+	void timer_collect(Ctx* c)
+	{
+		if (!c->timing) return;
+		for (int w = 0; w < 3; ++w)
+			if (c->ev_pending[w])
+			{
+				float ms = 0.f;
+				if (hipEventElapsedTime(&ms, c->ev[2 * w], c->ev[2 * w + 1]) == hipSuccess)
+				{
+					c->t_last[w] = ms;
+					c->t_total[w] += ms;
+					c->t_count[w] += 1;
+				}
+				c->ev_pending[w] = false;
+			}
+	}
+} // namespace gple
+
+// ---- context with a grow-only buffer pool ----------------------------------------------------------------
+struct gple_ctx: gple::Ctx
+{
+	struct PoolEntry
+	{
+		void* p;
+		size_t bytes;
+		bool used;
+	};
+	std::vector<PoolEntry> pool;
+	std::mutex pool_mu;
+	std::mutex call_mu; // serialises fit / predict calls that share the pooled scratch
+
+	double* acquire(size_t bytes, hipError_t* err)
+	{
+		std::lock_guard<std::mutex> lk(pool_mu);
+		*err = hipSuccess;
+		if (bytes == 0) bytes = 8;
+		PoolEntry* best = nullptr;
+		for (PoolEntry& e : pool)
+			if (!e.used && e.bytes >= bytes && e.bytes <= 2 * bytes + 4096 && (!best || e.bytes < best->bytes)) best = &e;
+		if (best)
+		{
+			best->used = true;
+			return static_cast<double*>(best->p);
+		}
+		void* p = nullptr;
+		*err = hipMalloc(&p, bytes);
+		if (*err != hipSuccess) return nullptr;
+		pool.push_back({p, bytes, true});
+		return static_cast<double*>(p);
+	}
+	void give_back(void* p)
+	{
+		if (!p) return;
+		std::lock_guard<std::mutex> lk(pool_mu);
+		for (PoolEntry& e : pool)
+			if (e.p == p) e.used = false;
+	}
+};
+
+namespace
+{
+	// pooled buffer with scope lifetime
+	struct Scratch
+	{
+		gple_ctx* ctx;
+		double* p = nullptr;
+		explicit Scratch(gple_ctx* c): ctx(c) {}
+		Scratch(const Scratch&) = delete;
+		~Scratch() { ctx->give_back(p); }
+		hipError_t get(size_t doubles)
+		{
+			hipError_t e;
+			p = ctx->acquire(doubles * sizeof(double), &e);
+			return e;
+		}
+	};
+
+	double nan_() { return std::numeric_limits<double>::quiet_NaN(); }
+
+	SEParam make_se(double amp, double n2, double l0, double l1) { return SEParam{amp, n2, l0, l1, 1.0 / l0, 1.0 / l1}; }
+
+	// kernel.h:285-294
+	SEParam purity_aux(double mag, double l0, double l1)
+	{
+		const double m = mag * mag * std::sqrt(l0 * l1);
+		return make_se(m * m, 0.0, std::sqrt(2.0) * l0, std::sqrt(2.0) * l1);
+	}
+
+	// copies `n` doubles host->device or device->device depending on the IO flag
+	hipError_t copy_in(hipStream_t s, double* dst, const double* src, size_t n, bool dev)
+	{
+		if (n == 0) return hipSuccess;
+		return hipMemcpyAsync(dst, src, n * sizeof(double), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+	}
+	hipError_t copy_out(hipStream_t s, double* dst, const double* src, size_t n, bool dev)
+	{
+		if (n == 0 || dst == nullptr) return hipSuccess;
+		return hipMemcpyAsync(dst, src, n * sizeof(double), dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s);
+	}
+} // namespace
+
+// ---- fit handles ---------------------------------------------------------------------------------------------
+struct FitCommon
+{
+	std::atomic<int> refs{1};
+	gple_ctx* ctx = nullptr;
+	int N = 0, Np = 0, n_total = 0;
+	unsigned flags = 0;
+	bool is_complex = false;
+	double* Xt = nullptr;   // 2*Np
+	double* ys = nullptr;   // n_total
+	double* T = nullptr;    // n_total^2
+	double* v = nullptr;    // n_total
+	double* w = nullptr;    // n_total (diag of K^-1)
+	double* wx = nullptr;   // Np (complex only)
+	double* W = nullptr;    // n_total^2, lazy
+	double* sdev = nullptr; // [0] rescale factor, [1..] raw sums, [31] info (as int)
+	double s_host = 0.0;
+	SEParamSet ps{};
+	double self = 0.0; // k(x*, x*)
+	std::mutex lazy_mu;
+
+	~FitCommon()
+	{
+		if (!ctx) return;
+		for (double* p : {Xt, ys, T, v, w, wx, W, sdev}) ctx->give_back(p);
+	}
+};
+struct gple_real_fit: FitCommon
+{
+	double theta[4];
+	gple_real_fit_scalars sc;
+};
+struct gple_complex_fit: FitCommon
+{
+	double theta[8];
+	gple_complex_fit_scalars sc;
+};
+
+namespace
+{
+	// K^-1 (explicit) on first request
+	int ensure_inverse(FitCommon* f)
+	{
+		std::lock_guard<std::mutex> lk(f->lazy_mu);
+		if (f->W) return GPLE_OK;
+		gple_ctx* ctx = f->ctx;
+		hipError_t e;
+		double* W = ctx->acquire(static_cast<size_t>(f->n_total) * f->n_total * sizeof(double), &e);
+		GPLE_HIP(ctx, e);
+		e = lauum_full(ctx->stream, f->T, f->n_total, W, f->n_total, f->n_total);
+		if (e != hipSuccess)
+		{
+			ctx->give_back(W);
+			GPLE_HIP(ctx, e);
+		}
+		f->W = W;
+		return GPLE_OK;
+	}
+
+	// shared front half of both fits: upload, label scaling, Gram, Cholesky, inverse factor, weights
+	int fit_common(gple_ctx* ctx, FitCommon* f, const double* X, const double* y, int y_stride, size_t N, unsigned flags)
+	{
+		hipStream_t st = ctx->stream;
+		const bool dev = flags & GPLE_IO_DEVICE;
+		f->ctx = ctx;
+		f->N = static_cast<int>(N);
+		f->Np = static_cast<int>(round_up(N, NPAD));
+		f->n_total = f->is_complex ? 2 * f->Np : f->Np;
+		f->flags = flags;
+		const int Np = f->Np, nt = f->n_total;
+		hipError_t e;
+		f->Xt = ctx->acquire(2 * static_cast<size_t>(Np) * 8, &e);
+		GPLE_HIP(ctx, e);
+		f->ys = ctx->acquire(static_cast<size_t>(nt) * 8, &e);
+		GPLE_HIP(ctx, e);
+		f->T = ctx->acquire(static_cast<size_t>(nt) * nt * 8, &e);
+		GPLE_HIP(ctx, e);
+		f->v = ctx->acquire(static_cast<size_t>(nt) * 8, &e);
+		GPLE_HIP(ctx, e);
+		f->w = ctx->acquire(static_cast<size_t>(nt) * 8, &e);
+		GPLE_HIP(ctx, e);
+		f->sdev = ctx->acquire(32 * 8, &e);
+		GPLE_HIP(ctx, e);
+		if (f->is_complex)
+		{
+			f->wx = ctx->acquire(static_cast<size_t>(Np) * 8, &e);
+			GPLE_HIP(ctx, e);
+		}
+		Scratch ytmp(ctx), Lbuf(ctx), work(ctx), part(ctx), u(ctx);
+		timer_start(ctx, GPLE_TIMER_FIT);
+		const size_t ylen = N * static_cast<size_t>(y_stride);
+		GPLE_HIP(ctx, ytmp.get(ylen));
+		GPLE_HIP(ctx, Lbuf.get(static_cast<size_t>(nt) * nt));
+		GPLE_HIP(ctx, work.get(static_cast<size_t>(nt) * nt / 4 + 64));
+		GPLE_HIP(ctx, part.get(static_cast<size_t>(nt / 256) * nt));
+		GPLE_HIP(ctx, u.get(nt));
+
+		GPLE_HIP(ctx, hipMemsetAsync(f->Xt, 0, 2 * static_cast<size_t>(Np) * 8, st));
+		GPLE_HIP(ctx, hipMemsetAsync(f->sdev, 0, 32 * 8, st));
+		GPLE_HIP(ctx, copy_in(st, f->Xt, X, 2 * N, dev));
+		GPLE_HIP(ctx, copy_in(st, ytmp.p, y, ylen, dev));
+		GPLE_HIP(ctx, launch_prep_labels(st, ytmp.p, y_stride, f->is_complex ? 1 : 0, f->N, Np, f->ys, f->sdev));
+		GPLE_HIP(ctx, hipMemsetAsync(f->T, 0, static_cast<size_t>(nt) * nt * 8, st));
+		GPLE_HIP(ctx, launch_gram_train(st, f->Xt, f->N, Np, nt, f->ps, Lbuf.p, nt));
+		int* info_dev = reinterpret_cast<int*>(f->sdev + 31);
+		GPLE_HIP(ctx, potrf_lower(st, Lbuf.p, nt, nt, f->T, nt, info_dev));
+		GPLE_HIP(ctx, trtri_lower_from_diag(st, Lbuf.p, nt, f->T, nt, nt, work.p));
+		GPLE_HIP(ctx, launch_trmv_lower(st, f->T, nt, nt, f->ys, part.p, u.p));
+		GPLE_HIP(ctx, launch_colpass(st, f->T, nt, nt, u.p, f->v, f->w, Np, f->wx));
+		return GPLE_OK;
+	}
+
+	template <typename S>
+	void fill_nan_scalars(S* sc)
+	{
+		double* d = reinterpret_cast<double*>(sc);
+		for (size_t i = 0; i < (sizeof(S) - sizeof(int)) / sizeof(double); ++i) d[i] = nan_();
+		sc->info = 0;
+	}
+
+	// complex raw sums: out[0] = LOOCV error, out[1] = Re(conj(ys).v) (both in the reference's complex convention)
+	__global__ void __launch_bounds__(1024) complex_fit_sums_kernel(const double* __restrict__ ys, const double* __restrict__ wv,
+		const double* __restrict__ wd, const double* __restrict__ wx, int N, int Np, double* __restrict__ out)
+	{
+		__shared__ double red[16];
+		double s0 = 0.0, s1 = 0.0;
+		for (int i = threadIdx.x; i < N; i += 1024)
+		{
+			// P_ii = (Mxx + Myy)/4, Q_ii = ((Mxx - Myy) - 2i Mxy)/4, v_i = (wx + i wy)/2   
+			const double mxx = wd[i], myy = wd[Np + i], mxy = wx[i];
+			const double p = 0.25 * (mxx + myy), qr = 0.25 * (mxx - myy), qi = -0.5 * mxy;
+			const double vr = 0.5 * wv[i], vi = 0.5 * wv[Np + i];
+			// numerator P v - conj(Q v)   (complex_kernel.cpp:281)
+			const double qvr = qr * vr - qi * vi, qvi = qr * vi + qi * vr;
+			const double nr = p * vr - qvr, ni = p * vi + qvi;
+			const double den = p * p - (qr * qr + qi * qi);
+			const double dr = nr / den, di = ni / den;
+			s0 += dr * dr + di * di;
+			s1 += ys[i] * vr + ys[Np + i] * vi;
+		}
+		for (int q = 0; q < 2; ++q)
+		{
+			double x = q == 0 ? s0 : s1;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+			__syncthreads();
+			if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+			__syncthreads();
+			if (threadIdx.x == 0)
+			{
+				double tot = 0.0;
+				for (int i = 0; i < 16; ++i) tot += red[i];
+				out[q] = tot;
+			}
+		}
+	}
+
+	// P / Q blocks of the augmented inverse from the real 2Np x 2Np inverse M (column-major, ld = 2 Np):
+	//   P = ((Mxx + Myy) + i (Mxy^T - Mxy)) / 4,   Q = ((Mxx - Myy) - i (Mxy + Mxy^T)) / 4
+	__global__ void __launch_bounds__(256) complex_blocks_kernel(const double* __restrict__ Mi, long ld, int N, int Np, int which,
+		double* __restrict__ out)
+	{
+		const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+		const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+		if (i >= N || j >= N) return;
+		const double mxx = Mi[i + j * ld], myy = Mi[(Np + i) + (Np + j) * ld];
+		const double mxy = Mi[i + (Np + j) * ld], mxyT = Mi[j + (Np + i) * ld];
+		double re, im;
+		if (which == 0) re = 0.25 * (mxx + myy), im = 0.25 * (mxyT - mxy);
+		else re = 0.25 * (mxx - myy), im = -0.25 * (mxy + mxyT);
+		out[2 * (i + static_cast<long>(j) * N)] = re;
+		out[2 * (i + static_cast<long>(j) * N) + 1] = im;
+	}
+	// K (real) and pseudo-kernel (complex) of the complex training set, regenerated for the getters
+	__global__ void __launch_bounds__(256) complex_kernels_kernel(const double* __restrict__ C, long ld, int N, int Np, int which,
+		double* __restrict__ out)
+	{
+		const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+		const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+		if (i >= N || j >= N) return;
+		const double cxx = C[i + j * ld], cyy = C[(Np + i) + (Np + j) * ld], cxy = C[i + (Np + j) * ld];
+		if (which == 0) out[i + static_cast<long>(j) * N] = cxx + cyy; // K = Cxx + Cyy
+		else
+		{
+			out[2 * (i + static_cast<long>(j) * N)] = cxx - cyy; // Re Kt
+			out[2 * (i + static_cast<long>(j) * N) + 1] = 2.0 * cxy; // Im Kt
+		}
+	}
+	__global__ void __launch_bounds__(256) halve_pair_kernel(const double* __restrict__ a, int N, int Np, double* __restrict__ out)
+	{
+		const int i = blockIdx.x * 256 + threadIdx.x;
+		if (i < N) out[2 * i] = 0.5 * a[i], out[2 * i + 1] = 0.5 * a[Np + i];
+	}
+	__global__ void __launch_bounds__(256) pair_kernel(const double* __restrict__ a, int N, int Np, double* __restrict__ out)
+	{
+		const int i = blockIdx.x * 256 + threadIdx.x;
+		if (i < N) out[2 * i] = a[i], out[2 * i + 1] = a[Np + i];
+	}
+} // namespace
+
+extern "C"
+{
+	const char* gple_status_string(int status)
+	{
+		switch (status)
+		{
+		case GPLE_OK: return "ok";
+		case GPLE_ERR_BAD_ARG: return "bad argument";
+		case GPLE_ERR_HIP: return "HIP runtime error";
+		case GPLE_ERR_ALLOC: return "device allocation failed";
+		case GPLE_ERR_STATE: return "requested output was not computed by this fit (flags)";
+		default: return "unknown status";
+		}
+	}
+
+	int gple_ctx_create(int device, void* stream, gple_ctx** out)
+	{
+		if (!out) return GPLE_ERR_BAD_ARG;
+		*out = nullptr;
+		int count = 0;
+		if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return GPLE_ERR_HIP;
+		if (hipSetDevice(device) != hipSuccess) return GPLE_ERR_HIP;
+		gple_ctx* c = new (std::nothrow) gple_ctx;
+		if (!c) return GPLE_ERR_ALLOC;
+		c->device = device;
+		if (stream) c->stream = static_cast<hipStream_t>(stream);
+		else
+		{
+			if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+			{
+				delete c;
+				return GPLE_ERR_HIP;
+			}
+			c->owns_stream = true;
+		}
+		if (hipHostMalloc(reinterpret_cast<void**>(&c->host_scalars), 64 * sizeof(double)) != hipSuccess)
+		{
+			if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+			delete c;
+			return GPLE_ERR_ALLOC;
+		}
+		*out = c;
+		return GPLE_OK;
+	}
+	int gple_ctx_destroy(gple_ctx* ctx)
+	{
+		if (!ctx) return GPLE_OK;
+		(void)hipSetDevice(ctx->device);
+		(void)hipStreamSynchronize(ctx->stream);
+		for (auto& e : ctx->pool) (void)hipFree(e.p);
+		if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
+		for (hipEvent_t e : ctx->ev)
+			if (e) (void)hipEventDestroy(e);
+		if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+		delete ctx;
+		return GPLE_OK;
+	}
+	int gple_ctx_synchronize(gple_ctx* ctx)
+	{
+		if (!ctx) return GPLE_ERR_BAD_ARG;
+		GPLE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		return GPLE_OK;
+	}
+	const char* gple_ctx_last_error(const gple_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+	int gple_ctx_enable_timing(gple_ctx* ctx, int on)
+	{
+		if (!ctx) return GPLE_ERR_BAD_ARG;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		if (on && !ctx->ev[0])
+			for (hipEvent_t& e : ctx->ev) GPLE_HIP(ctx, hipEventCreate(&e));
+		ctx->timing = on != 0;
+		for (int w = 0; w < 3; ++w) ctx->t_last[w] = ctx->t_total[w] = 0.0, ctx->t_count[w] = 0, ctx->ev_pending[w] = false;
+		return GPLE_OK;
+	}
+	int gple_ctx_get_timing(gple_ctx* ctx, gple_timer which, double* last_ms, double* total_ms, long* count)
+	{
+		if (!ctx || which < 0 || which > 2) return GPLE_ERR_BAD_ARG;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		if (last_ms) *last_ms = ctx->t_last[which];
+		if (total_ms) *total_ms = ctx->t_total[which];
+		if (count) *count = ctx->t_count[which];
+		return GPLE_OK;
+	}
+
+	// ---- KernelBase --------------------------------------------------------------------------------------------
+	int gple_real_gram(gple_ctx* ctx, const double theta[4], const double* left, size_t R, const double* right, size_t C,
+		int same_features, unsigned flags, double* K, double* dK)
+	{
+		if (!ctx || !theta || !K || (R && !left) || (C && !right)) return GPLE_ERR_BAD_ARG;
+		if (R == 0 || C == 0) return GPLE_OK;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		const bool dev = flags & GPLE_IO_DEVICE;
+		const SEParam p = make_se(theta[0] * theta[0], theta[3] * theta[3], theta[1], theta[2]);
+		if (dev)
+		{
+			GPLE_HIP(ctx, launch_gram_rect(st, left, (int)R, right, (int)C, same_features, p, theta[0], theta[3], K, dK));
+			return GPLE_OK;
+		}
+		Scratch l(ctx), r(ctx), k(ctx), dk(ctx);
+		GPLE_HIP(ctx, l.get(2 * R));
+		GPLE_HIP(ctx, r.get(2 * C));
+		GPLE_HIP(ctx, k.get(R * C));
+		if (dK) GPLE_HIP(ctx, dk.get(4 * R * C));
+		GPLE_HIP(ctx, copy_in(st, l.p, left, 2 * R, false));
+		GPLE_HIP(ctx, copy_in(st, r.p, right, 2 * C, false));
+		GPLE_HIP(ctx, launch_gram_rect(st, l.p, (int)R, r.p, (int)C, same_features, p, theta[0], theta[3], k.p, dK ? dk.p : nullptr));
+		GPLE_HIP(ctx, copy_out(st, K, k.p, R * C, false));
+		if (dK) GPLE_HIP(ctx, copy_out(st, dK, dk.p, 4 * R * C, false));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		return GPLE_OK;
+	}
+
+	int gple_cutoff_factor(gple_ctx* ctx, const double* prediction, int is_complex, const double* variance, size_t M, unsigned flags,
+		double* factor)
+	{
+		if (!ctx || (M && (!prediction || !variance || !factor))) return GPLE_ERR_BAD_ARG;
+		if (M == 0) return GPLE_OK;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		if (flags & GPLE_IO_DEVICE)
+		{
+			GPLE_HIP(ctx, launch_cutoff(st, prediction, is_complex, variance, (int)M, factor));
+			return GPLE_OK;
+		}
+		const size_t pl = is_complex ? 2 * M : M;
+		Scratch p(ctx), v(ctx), f(ctx);
+		GPLE_HIP(ctx, p.get(pl));
+		GPLE_HIP(ctx, v.get(M));
+		GPLE_HIP(ctx, f.get(M));
+		GPLE_HIP(ctx, copy_in(st, p.p, prediction, pl, false));
+		GPLE_HIP(ctx, copy_in(st, v.p, variance, M, false));
+		GPLE_HIP(ctx, launch_cutoff(st, p.p, is_complex, v.p, (int)M, f.p));
+		GPLE_HIP(ctx, copy_out(st, factor, f.p, M, false));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		return GPLE_OK;
+	}
+
+	// ---- TrainingKernel ----------------------------------------------------------------------------------------
+	int gple_real_fit_create(gple_ctx* ctx, const double theta[4], const double* X, const double* y, int y_is_complex, size_t N,
+		unsigned flags, gple_real_fit_scalars* scalars, gple_real_fit** out)
+	{
+		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 20)) return GPLE_ERR_BAD_ARG;
+		*out = nullptr;
+		if (flags & GPLE_CALC_DERIVATIVE) return GPLE_ERR_STATE; // TODO(round 1): derivative path
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		gple_real_fit* f = new (std::nothrow) gple_real_fit;
+		if (!f) return GPLE_ERR_ALLOC;
+		std::memcpy(f->theta, theta, sizeof(f->theta));
+		const double sf = theta[0], l0 = theta[1], l1 = theta[2], sn = theta[3];
+		f->ps.p[0] = f->ps.p[1] = f->ps.p[2] = make_se(sf * sf, sn * sn, l0, l1);
+		f->self = (sf * sf) * (1.0 + (sn * sn) * 1.0); // KernelBase(params, col, col).get_kernel().value(), kernel.cpp:512
+		hipStream_t st = ctx->stream;
+		int status = fit_common(ctx, f, X, y, y_is_complex ? 2 : 1, N, flags);
+		if (status == GPLE_OK)
+		{
+			hipError_t e = launch_real_fit_sums(st, f->Xt, f->ys, f->v, f->w, f->N, f->sdev + 1);
+			if (e == hipSuccess && (flags & GPLE_CALC_AVERAGE))
+			{
+				Scratch part(ctx);
+				const size_t g = (N + 63) / 64;
+				e = part.get(g * g);
+				if (e == hipSuccess) e = launch_quadform(st, f->Xt, f->N, purity_aux(sf, l0, l1), f->v, f->v, part.p, f->sdev + 6);
+			}
+			if (e == hipSuccess) e = hipMemcpyAsync(ctx->host_scalars, f->sdev, 32 * 8, hipMemcpyDeviceToHost, st);
+			timer_stop(ctx, GPLE_TIMER_FIT);
+			if (e == hipSuccess) e = hipStreamSynchronize(st);
+			timer_collect(ctx);
+			if (e != hipSuccess) status = record_hip_error(ctx, e, "real fit reductions", __LINE__);
+		}
+		if (status != GPLE_OK)
+		{
+			(void)hipStreamSynchronize(st);
+			delete f;
+			return status;
+		}
+		const double* h = ctx->host_scalars;
+		gple_real_fit_scalars& sc = f->sc;
+		fill_nan_scalars(&sc);
+		int info_i;
+		std::memcpy(&info_i, h + 31, sizeof(int));
+		sc.info = info_i;
+		const double s = h[0];
+		f->s_host = s;
+		sc.rescale_factor = s;
+		{
+			const double within = h[5] / static_cast<double>(N); // kernel.h:169
+			sc.magnitude = within < 0 ? std::sqrt(-within) : std::sqrt(within);
+		}
+		if (flags & GPLE_CALC_ERROR) sc.error = h[1];
+		if (flags & GPLE_CALC_AVERAGE)
+		{
+			const double GlobalFactor = 2.0 * M_PI; // power<Dim>(2 pi), kernel.cpp:291
+			const double lprod = l0 * l1;
+			sc.population = GlobalFactor * (sf * sf) * lprod * h[2] / s;                 // :293
+			sc.first_order_average[0] = GlobalFactor * (sf * sf) * lprod * h[3] / s;     // :308
+			sc.first_order_average[1] = GlobalFactor * (sf * sf) * lprod * h[4] / s;
+			const double PurityGlobal = (2.0 * M_PI) * M_PI; // PurityFactor * pi^Dim, :330
+			sc.purity = PurityGlobal * h[6] / (s * s);        // :331
+		}
+		if (scalars) *scalars = sc;
+		*out = f;
+		return GPLE_OK;
+	}
+	int gple_real_fit_retain(gple_real_fit* fit)
+	{
+		if (!fit) return GPLE_ERR_BAD_ARG;
+		fit->refs.fetch_add(1);
+		return GPLE_OK;
+	}
+	int gple_real_fit_release(gple_real_fit* fit)
+	{
+		if (!fit) return GPLE_OK;
+		if (fit->refs.fetch_sub(1) == 1)
+		{
+			(void)hipStreamSynchronize(fit->ctx->stream);
+			delete fit;
+		}
+		return GPLE_OK;
+	}
+	size_t gple_real_fit_size(const gple_real_fit* fit) { return fit ? fit->N : 0; }
+
+	int gple_real_fit_get(gple_real_fit* f, gple_real_array which, unsigned flags, double* dst)
+	{
+		if (!f || !dst) return GPLE_ERR_BAD_ARG;
+		gple_ctx* ctx = f->ctx;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		const bool dev = flags & GPLE_IO_DEVICE;
+		const size_t N = f->N;
+		const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+		switch (which)
+		{
+		case GPLE_R_KERNEL:
+		{
+			Scratch k(ctx);
+			GPLE_HIP(ctx, k.get(N * N));
+			GPLE_HIP(ctx, launch_gram_rect(st, f->Xt, (int)N, f->Xt, (int)N, 1, f->ps.p[0], f->theta[0], f->theta[3], k.p, nullptr));
+			GPLE_HIP(ctx, hipMemcpyAsync(dst, k.p, N * N * 8, kind, st));
+			GPLE_HIP(ctx, hipStreamSynchronize(st));
+			break;
+		}
+		case GPLE_R_INVERSE:
+			GPLE_TRY(ensure_inverse(f));
+			GPLE_HIP(ctx, hipMemcpy2DAsync(dst, N * 8, f->W, static_cast<size_t>(f->n_total) * 8, N * 8, N, kind, st));
+			break;
+		case GPLE_R_INVLBL: GPLE_HIP(ctx, hipMemcpyAsync(dst, f->v, N * 8, kind, st)); break;
+		case GPLE_R_LABEL: GPLE_HIP(ctx, hipMemcpyAsync(dst, f->ys, N * 8, kind, st)); break;
+		case GPLE_R_INVERSE_DIAG: GPLE_HIP(ctx, hipMemcpyAsync(dst, f->w, N * 8, kind, st)); break;
+		case GPLE_R_INVLBL_DERIV: return GPLE_ERR_STATE;
+		default: return GPLE_ERR_BAD_ARG;
+		}
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		return GPLE_OK;
+	}
+
+	// ---- PredictiveKernel --------------------------------------------------------------------------------------
+	static int predict_common(gple_ctx* ctx, const FitCommon* f, const double* Xs, size_t M, unsigned flags, const double* labels,
+		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars)
+	{
+		if (scalars)
+		{
+			scalars->error = nan_();
+			for (double& d : scalars->error_derivative) d = nan_();
+		}
+		if (M == 0) return GPLE_OK;
+		if ((flags & GPLE_CALC_DERIVATIVE) && labels) return GPLE_ERR_STATE; // TODO(round 1): derivative path
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		const bool dev = flags & GPLE_IO_DEVICE;
+		const bool cplx = f->is_complex;
+		const int Mi = static_cast<int>(M);
+		const int Mh = static_cast<int>(round_up(M, 128));
+		const int m_rows = cplx ? 2 * Mh : Mh;
+		const size_t ow = cplx ? 2 : 1; // doubles per prediction entry
+		Scratch xs(ctx), q(ctx), mu(ctx), lab(ctx), o_mean(ctx), o_var(ctx), o_cut(ctx), epart(ctx);
+		timer_start(ctx, GPLE_TIMER_PREDICT);
+		const double* xs_dev = Xs;
+		if (!dev)
+		{
+			GPLE_HIP(ctx, xs.get(2 * M));
+			GPLE_HIP(ctx, copy_in(st, xs.p, Xs, 2 * M, false));
+			xs_dev = xs.p;
+		}
+		GPLE_HIP(ctx, q.get(m_rows));
+		GPLE_HIP(ctx, mu.get(m_rows));
+		PredictArgs a{};
+		a.Xs = xs_dev, a.M = Mi, a.m_rows = m_rows, a.m_split = cplx ? Mh : m_rows;
+		a.Xt = f->Xt, a.N = f->N, a.n_total = f->n_total, a.n_split = cplx ? f->Np : f->n_total;
+		a.T = f->T, a.ldt = f->n_total, a.v = f->v, a.q = q.p, a.mu = mu.p, a.ps = f->ps;
+		timer_start(ctx, GPLE_TIMER_PREDICT_KERNEL);
+		GPLE_HIP(ctx, launch_predict_q(st, a));
+		timer_stop(ctx, GPLE_TIMER_PREDICT_KERNEL);
+		const double* lab_dev = labels;
+		if (labels && !dev)
+		{
+			GPLE_HIP(ctx, lab.get(ow * M));
+			GPLE_HIP(ctx, copy_in(st, lab.p, labels, ow * M, false));
+			lab_dev = lab.p;
+		}
+		double *d_mean = prediction, *d_var = variance, *d_cut = cutoff_prediction;
+		if (!dev)
+		{
+			if (prediction)
+			{
+				GPLE_HIP(ctx, o_mean.get(ow * M));
+				d_mean = o_mean.p;
+			}
+			if (variance)
+			{
+				GPLE_HIP(ctx, o_var.get(M));
+				d_var = o_var.p;
+			}
+			if (cutoff_prediction)
+			{
+				GPLE_HIP(ctx, o_cut.get(ow * M));
+				d_cut = o_cut.p;
+			}
+		}
+		const int nblk = (Mi + 255) / 256;
+		double* err_part = nullptr;
+		if (labels)
+		{
+			GPLE_HIP(ctx, epart.get(nblk + 1));
+			err_part = epart.p;
+		}
+		if (cplx)
+			GPLE_HIP(ctx, launch_predict_finish_complex(st, q.p, mu.p, Mi, Mh, f->self, f->sdev, lab_dev, d_mean, d_var, d_cut, err_part));
+		else
+			GPLE_HIP(ctx, launch_predict_finish_real(st, q.p, mu.p, Mi, f->self, f->sdev, lab_dev, d_mean, d_var, d_cut, err_part));
+		if (labels)
+		{
+			GPLE_HIP(ctx, launch_sum(st, err_part, nblk, err_part + nblk));
+			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 32, err_part + nblk, 8, hipMemcpyDeviceToHost, st));
+		}
+		if (!dev)
+		{
+			GPLE_HIP(ctx, copy_out(st, prediction, d_mean, ow * M, false));
+			GPLE_HIP(ctx, copy_out(st, variance, d_var, M, false));
+			GPLE_HIP(ctx, copy_out(st, cutoff_prediction, d_cut, ow * M, false));
+		}
+		timer_stop(ctx, GPLE_TIMER_PREDICT);
+		// host outputs (and the error scalar) need the stream drained; device-pointer calls without labels stay asynchronous
+		// (pooled scratch is only ever reused by later work on this same stream, which the stream orders)
+		if (!dev || labels || ctx->timing)
+		{
+			GPLE_HIP(ctx, hipStreamSynchronize(st));
+			timer_collect(ctx);
+		}
+		if (labels && scalars) scalars->error = ctx->host_scalars[32];
+		return GPLE_OK;
+	}
+
+	int gple_real_predict(gple_ctx* ctx, const gple_real_fit* fit, const double* Xs, size_t M, unsigned flags, const double* labels,
+		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars)
+	{
+		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
+		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
+	}
+
+	// ---- TrainingComplexKernel ------------------------------------------------------------------------------
+	int gple_complex_fit_create(gple_ctx* ctx, const double theta[8], const double* X, const double* y, size_t N, unsigned flags,
+		gple_complex_fit_scalars* scalars, gple_complex_fit** out)
+	{
+		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 19)) return GPLE_ERR_BAD_ARG;
+		*out = nullptr;
+		if (flags & GPLE_CALC_DERIVATIVE) return GPLE_ERR_STATE; // TODO(round 1): derivative path
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		gple_complex_fit* f = new (std::nothrow) gple_complex_fit;
+		if (!f) return GPLE_ERR_ALLOC;
+		f->is_complex = true;
+		std::memcpy(f->theta, theta, sizeof(f->theta));
+		const double s0 = theta[0], sR = theta[1], lR0 = theta[2], lR1 = theta[3], sI = theta[4], lI0 = theta[5], lI1 = theta[6],
+					 sn = theta[7];
+		// correlation kernel parameters, complex_kernel.cpp:144-157
+		const double ss0 = lR0 * lR0 + lI0 * lI0, ss1 = lR1 * lR1 + lI1 * lI1;
+		const double sC = std::sqrt(sR * sI * ((2.0 * lR0 * lI0 / ss0) * (2.0 * lR1 * lI1 / ss1)));
+		const double lC0 = std::sqrt(ss0 / 2.0), lC1 = std::sqrt(ss1 / 2.0);
+		const double m2 = s0 * s0;
+		// blocks of the real covariance of [Re; Im]: Cxx = s^2 (kR + sn^2/2 d), Cyy = s^2 (kI + sn^2/2 d), Cxy = s^2 kC
+		f->ps.p[0] = make_se(m2 * (sR * sR), (sn * sn) / (2.0 * sR * sR), lR0, lR1);
+		f->ps.p[1] = make_se(m2 * (sC * sC), 0.0, lC0, lC1);
+		f->ps.p[2] = make_se(m2 * (sI * sI), (sn * sn) / (2.0 * sI * sI), lI0, lI1);
+		f->self = m2 * (sR * sR * (1.0 + 0.0) + sI * sI * (1.0 + 0.0) + sn * sn * 1.0); // complex_kernel.cpp:632
+		hipStream_t st = ctx->stream;
+		int status = fit_common(ctx, f, X, y, 2, N, flags);
+		double purity_sums[6] = {0, 0, 0, 0, 0, 0};
+		if (status == GPLE_OK)
+		{
+			hipLaunchKernelGGL(complex_fit_sums_kernel, dim3(1), dim3(1024), 0, st, f->ys, f->v, f->w, f->wx, f->N, f->Np, f->sdev + 1);
+			hipError_t e = hipGetLastError();
+			if (e == hipSuccess && (flags & GPLE_CALC_AVERAGE))
+			{
+				// purity quadratic forms in the [Re; Im] weights w = 2 v (complex_kernel.cpp:287-377):
+				// Re(v^H K1 v) + Re(v^T K2 v) = 2 vr'KR'vr + 2 vi'KI'vi + 2 (vr'KC'vr + vi'KC'vi) + 4 vr'(KRC + KIC)vi
+				Scratch part(ctx);
+				const size_t g = (N + 63) / 64;
+				e = part.get(g * g);
+				const SEParam aR = purity_aux(sR, lR0, lR1), aI = purity_aux(sI, lI0, lI1), aC = purity_aux(sC, lC0, lC1);
+				auto mixed = [](double m1, double a0, double a1, double mb, double b0, double b1) { // complex_kernel.cpp:206-219
+					const double prod = (0.5 * (1.0 / (a0 * a0) + 1.0 / (b0 * b0))) * (0.5 * (1.0 / (a1 * a1) + 1.0 / (b1 * b1)));
+					const double m = m1 * mb / std::sqrt(std::sqrt(prod));
+					return make_se(m * m, 0.0, std::sqrt(a0 * a0 + b0 * b0), std::sqrt(a1 * a1 + b1 * b1));
+				};
+				const SEParam aRC = mixed(sR, lR0, lR1, sC, lC0, lC1), aIC = mixed(sI, lI0, lI1, sC, lC0, lC1);
+				const double *wr = f->v, *wi = f->v + f->Np;
+				const SEParam ks[6] = {aR, aI, aC, aC, aRC, aIC};
+				const double* as[6] = {wr, wi, wr, wi, wr, wr};
+				const double* bs[6] = {wr, wi, wr, wi, wi, wi};
+				for (int q = 0; q < 6 && e == hipSuccess; ++q) e = launch_quadform(st, f->Xt, f->N, ks[q], as[q], bs[q], part.p, f->sdev + 8 + q);
+			}
+			if (e == hipSuccess) e = hipMemcpyAsync(ctx->host_scalars, f->sdev, 32 * 8, hipMemcpyDeviceToHost, st);
+			timer_stop(ctx, GPLE_TIMER_FIT);
+			if (e == hipSuccess) e = hipStreamSynchronize(st);
+			timer_collect(ctx);
+			if (e != hipSuccess) status = record_hip_error(ctx, e, "complex fit reductions", __LINE__);
+		}
+		if (status != GPLE_OK)
+		{
+			(void)hipStreamSynchronize(st);
+			delete f;
+			return status;
+		}
+		const double* h = ctx->host_scalars;
+		for (int q = 0; q < 6; ++q) purity_sums[q] = h[8 + q];
+		gple_complex_fit_scalars& sc = f->sc;
+		fill_nan_scalars(&sc);
+		int info_i;
+		std::memcpy(&info_i, h + 31, sizeof(int));
+		sc.info = info_i;
+		const double s = h[0];
+		f->s_host = s;
+		sc.rescale_factor = s;
+		{
+			const double within = h[2] / static_cast<double>(N); // complex_kernel.h:194
+			sc.magnitude = within < 0 ? std::sqrt(-within) : std::sqrt(within);
+		}
+		if (flags & GPLE_CALC_ERROR) sc.error = h[1];
+		if (flags & GPLE_CALC_AVERAGE)
+		{
+			const double GlobalFactor = (2.0 * M_PI) * 2.0 * M_PI; // PurityFactor * 2 pi^Dim, complex_kernel.cpp:369
+			const double ThisTimeFactor = GlobalFactor * ((s0 * s0) * (s0 * s0));
+			// weights w = 2 v  ->  every quadratic form carries 1/4
+			const double qf = 0.25 * (2.0 * purity_sums[0] + 2.0 * purity_sums[1] + 2.0 * (purity_sums[2] + purity_sums[3])
+				+ 4.0 * (purity_sums[4] + purity_sums[5]));
+			sc.purity = ThisTimeFactor * qf / (s * s); // :373
+		}
+		if (scalars) *scalars = sc;
+		*out = f;
+		return GPLE_OK;
+	}
+	int gple_complex_fit_retain(gple_complex_fit* fit)
+	{
+		if (!fit) return GPLE_ERR_BAD_ARG;
+		fit->refs.fetch_add(1);
+		return GPLE_OK;
+	}
+	int gple_complex_fit_release(gple_complex_fit* fit)
+	{
+		if (!fit) return GPLE_OK;
+		if (fit->refs.fetch_sub(1) == 1)
+		{
+			(void)hipStreamSynchronize(fit->ctx->stream);
+			delete fit;
+		}
+		return GPLE_OK;
+	}
+	size_t gple_complex_fit_size(const gple_complex_fit* fit) { return fit ? fit->N : 0; }
+
+	int gple_complex_fit_get(gple_complex_fit* f, gple_complex_array which, unsigned flags, double* dst)
+	{
+		if (!f || !dst) return GPLE_ERR_BAD_ARG;
+		gple_ctx* ctx = f->ctx;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		const bool dev = flags & GPLE_IO_DEVICE;
+		const size_t N = f->N;
+		const int Np = f->Np, nt = f->n_total;
+		const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+		Scratch tmp(ctx), big(ctx);
+		const dim3 grid2((N + 63) / 64, (N + 3) / 4), blk(256);
+		switch (which)
+		{
+		case GPLE_C_KERNEL:
+		case GPLE_C_PSEUDO:
+		{
+			const size_t len = which == GPLE_C_KERNEL ? N * N : 2 * N * N;
+			GPLE_HIP(ctx, big.get(static_cast<size_t>(nt) * nt));
+			GPLE_HIP(ctx, tmp.get(len));
+			GPLE_HIP(ctx, launch_gram_train(st, f->Xt, f->N, Np, nt, f->ps, big.p, nt));
+			hipLaunchKernelGGL(complex_kernels_kernel, grid2, blk, 0, st, big.p, nt, (int)N, Np, which == GPLE_C_KERNEL ? 0 : 1, tmp.p);
+			GPLE_HIP(ctx, hipGetLastError());
+			GPLE_HIP(ctx, hipMemcpyAsync(dst, tmp.p, len * 8, kind, st));
+			break;
+		}
+		case GPLE_C_UPPER_LEFT:
+		case GPLE_C_LOWER_LEFT:
+			GPLE_TRY(ensure_inverse(f));
+			GPLE_HIP(ctx, tmp.get(2 * N * N));
+			hipLaunchKernelGGL(complex_blocks_kernel, grid2, blk, 0, st, f->W, nt, (int)N, Np, which == GPLE_C_UPPER_LEFT ? 0 : 1, tmp.p);
+			GPLE_HIP(ctx, hipGetLastError());
+			GPLE_HIP(ctx, hipMemcpyAsync(dst, tmp.p, 2 * N * N * 8, kind, st));
+			break;
+		case GPLE_C_INVLBL:
+			GPLE_HIP(ctx, tmp.get(2 * N));
+			hipLaunchKernelGGL(halve_pair_kernel, dim3((N + 255) / 256), blk, 0, st, f->v, (int)N, Np, tmp.p);
+			GPLE_HIP(ctx, hipGetLastError());
+			GPLE_HIP(ctx, hipMemcpyAsync(dst, tmp.p, 2 * N * 8, kind, st));
+			break;
+		case GPLE_C_LABEL:
+			GPLE_HIP(ctx, tmp.get(2 * N));
+			hipLaunchKernelGGL(pair_kernel, dim3((N + 255) / 256), blk, 0, st, f->ys, (int)N, Np, tmp.p);
+			GPLE_HIP(ctx, hipGetLastError());
+			GPLE_HIP(ctx, hipMemcpyAsync(dst, tmp.p, 2 * N * 8, kind, st));
+			break;
+		case GPLE_C_INVLBL_DERIV: return GPLE_ERR_STATE;
+		default: return GPLE_ERR_BAD_ARG;
+		}
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		return GPLE_OK;
+	}
+
+	int gple_complex_predict(gple_ctx* ctx, const gple_complex_fit* fit, const double* Xs, size_t M, unsigned flags, const double* labels,
+		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars)
+	{
+		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
+		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
+	}
+
+	// ---- not yet on the device (round 1 TODO): fail loudly, never fall back to the CPU ---------------------------
+	int gple_loose_function(gple_ctx*, const double*, size_t, const double*, const double*, size_t, const double*, const double*, size_t,
+		double*, double*)
+	{
+		return GPLE_ERR_STATE;
+	}
+	int gple_nlml(gple_ctx*, const double[4], const double*, const double*, size_t, double*, double*) { return GPLE_ERR_STATE; }
+	int gple_nlml_predict(gple_ctx*, const double[4], const double*, const double*, size_t, const double*, size_t, unsigned, double*)
+	{
+		return GPLE_ERR_STATE;
+	}
+}

@@ -1,0 +1,213 @@
+// gple_gemm.hip — fp64 MFMA (v_mfma_f64_16x16x4_f64) GEMM family for gfx950.
+//
+// Used by the dense part of the fit (reference hot loops 2,3,5: Eigen LDLT / solve(Identity) / -W dK W,
+// kernel.cpp:281-283, 354-358): Cholesky trailing updates and panel solves, the triangular inverse and T^T T.
+//
+//   C(m,n) = alpha * sum_k A(m,k) B(n,k) + beta * C(m,n)
+//
+// One workgroup = 4 waves (2 x 2) computes a BM x BN tile (64x64 or 128x128); K advances in steps of 16 through a
+// double-buffered LDS stage; every wave owns a (BM/2) x (BN/2) sub-tile held in VGPR-form MFMA accumulators
+// (launch bound 256 threads x 2 waves/SIMD caps the budget at 256 VGPRs, which keeps hipcc from bouncing the
+// accumulators between AGPRs and VGPRs every iteration — measured 35 vs 78 TFLOP/s on MI355X).
+//
+// Fragment maps of v_mfma_f64_16x16x4_f64 (verified on hardware, probes/mfma_f64_probe.hip):
+//   first operand  X[i = lane & 15][k = lane >> 4]   (16 x 4),
+//   second operand Y[k = lane >> 4][j = lane & 15]   (4 x 16),
+//   result         D[i = (lane >> 4) + 4 * reg][j = lane & 15].
+// The operand that should end up contiguous in memory is therefore fed as the SECOND operand.
+#include "gple_internal.h"
+
+namespace gple
+{
+	typedef double d4 __attribute__((ext_vector_type(4)));
+	typedef double d2 __attribute__((ext_vector_type(2)));
+
+	namespace
+	{
+		constexpr int BK = 16;
+		constexpr int LPAD = 16; // row stride (R + 16) doubles: the 4 k-rows of a fragment read hit disjoint bank halves
+
+		// Stages an R x 16 operand tile (rows r, depth k) from HBM into LDS as S[k][r].
+		template <int R, bool KMAJOR>
+		struct TileLoader
+		{
+			static constexpr int NV = R * BK / 2 / 256; // double2 per thread
+			static constexpr int RS = R + LPAD;
+			d2 v[NV];
+			__device__ __forceinline__ void load(const double* __restrict__ base, long ld, int t)
+			{
+				if constexpr (!KMAJOR)
+				{
+#pragma unroll
+					for (int q = 0; q < NV; ++q)
+					{
+						const int i = t + 256 * q;
+						const int r2 = (i % (R / 2)) * 2, k = i / (R / 2);
+						v[q] = *reinterpret_cast<const d2*>(base + r2 + static_cast<long>(k) * ld);
+					}
+				}
+				else
+				{
+					constexpr int TPR = 8 / NV; // threads per row
+					const int r = t / TPR, kofs = (t % TPR) * (2 * NV);
+#pragma unroll
+					for (int q = 0; q < NV; ++q)
+						v[q] = *reinterpret_cast<const d2*>(base + kofs + 2 * q + static_cast<long>(r) * ld);
+				}
+			}
+			__device__ __forceinline__ void store(double* __restrict__ S, int t) const
+			{
+				if constexpr (!KMAJOR)
+				{
+#pragma unroll
+					for (int q = 0; q < NV; ++q)
+					{
+						const int i = t + 256 * q;
+						const int r2 = (i % (R / 2)) * 2, k = i / (R / 2);
+						*reinterpret_cast<d2*>(S + k * RS + r2) = v[q];
+					}
+				}
+				else
+				{
+					constexpr int TPR = 8 / NV;
+					const int r = t / TPR, kofs = (t % TPR) * (2 * NV);
+#pragma unroll
+					for (int q = 0; q < NV; ++q)
+					{
+						S[(kofs + 2 * q) * RS + r] = v[q].x;
+						S[(kofs + 2 * q + 1) * RS + r] = v[q].y;
+					}
+				}
+			}
+		};
+
+		template <int BM, int BN, bool AK, bool BKM, bool CT>
+		__global__ void __launch_bounds__(256, 2) gemm_f64_kernel(const GemmDesc g)
+		{
+			constexpr int WTM = BM / 2, WTN = BN / 2;
+			constexpr int TM = WTM / 16, TN = WTN / 16;
+			constexpr int AS = BM + LPAD, BS = BN + LPAD;
+			__shared__ __attribute__((aligned(16))) double lds[2 * BK * AS + 2 * BK * BS];
+			double* const As = lds;
+			double* const Bs = lds + 2 * BK * AS;
+
+			const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+			const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+			if (g.lower_only && n0 >= m0 + BM) return;
+			int kb = 0, ke = g.K;
+			if (g.krange == K_GE_N) kb = n0;
+			else if (g.krange == K_LE_M) ke = min(g.K, m0 + BM);
+			else if (g.krange == K_GE_MAX_MN) kb = max(m0, n0);
+			kb = kb / BK * BK;
+			const int nk = (ke - kb + BK - 1) / BK;
+
+			const double* __restrict__ A = g.A + blockIdx.z * g.strideA;
+			const double* __restrict__ B = g.B + blockIdx.z * g.strideB;
+			double* __restrict__ C = g.C + blockIdx.z * g.strideC;
+			// address of operand element (r0, k)
+			auto a_at = [&](int k) { return AK ? A + k + static_cast<long>(m0) * g.lda : A + m0 + static_cast<long>(k) * g.lda; };
+			auto b_at = [&](int k) { return BKM ? B + k + static_cast<long>(n0) * g.ldb : B + n0 + static_cast<long>(k) * g.ldb; };
+
+			d4 acc[TM][TN];
+#pragma unroll
+			for (int i = 0; i < TM; ++i)
+#pragma unroll
+				for (int j = 0; j < TN; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+			TileLoader<BM, AK> la;
+			TileLoader<BN, BKM> lb;
+			if (nk > 0)
+			{
+				la.load(a_at(kb), g.lda, t);
+				lb.load(b_at(kb), g.ldb, t);
+				la.store(As, t);
+				lb.store(Bs, t);
+			}
+			__syncthreads();
+			const int fk = lane >> 4, fr = lane & 15;
+			for (int it = 0; it < nk; ++it)
+			{
+				const int cur = it & 1;
+				if (it + 1 < nk)
+				{
+					la.load(a_at(kb + (it + 1) * BK), g.lda, t);
+					lb.load(b_at(kb + (it + 1) * BK), g.ldb, t);
+				}
+				const double* __restrict__ a = As + cur * BK * AS + wm * WTM + fr;
+				const double* __restrict__ b = Bs + cur * BK * BS + wn * WTN + fr;
+#pragma unroll
+				for (int kk = 0; kk < BK; kk += 4)
+				{
+					double af[TM], bf[TN];
+#pragma unroll
+					for (int i = 0; i < TM; ++i) af[i] = a[(kk + fk) * AS + i * 16];
+#pragma unroll
+					for (int j = 0; j < TN; ++j) bf[j] = b[(kk + fk) * BS + j * 16];
+#pragma unroll
+					for (int i = 0; i < TM; ++i)
+#pragma unroll
+						for (int j = 0; j < TN; ++j)
+						{
+							if constexpr (CT) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+							else acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+						}
+				}
+				if (it + 1 < nk)
+				{
+					la.store(As + (cur ^ 1) * BK * AS, t);
+					lb.store(Bs + (cur ^ 1) * BK * BS, t);
+				}
+				__syncthreads();
+			}
+
+			const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+			for (int i = 0; i < TM; ++i)
+#pragma unroll
+				for (int j = 0; j < TN; ++j)
+#pragma unroll
+					for (int r = 0; r < 4; ++r)
+					{
+						long idx;
+						if constexpr (CT)
+						{
+							const int m = m0 + wm * WTM + i * 16 + fk + 4 * r, n = n0 + wn * WTN + j * 16 + fr;
+							idx = n + static_cast<long>(m) * g.ldc;
+						}
+						else
+						{
+							const int m = m0 + wm * WTM + i * 16 + fr, n = n0 + wn * WTN + j * 16 + fk + 4 * r;
+							idx = m + static_cast<long>(n) * g.ldc;
+						}
+						double val = alpha * acc[i][j][r];
+						if (beta != 0.0) val += beta * C[idx];
+						C[idx] = val;
+					}
+		}
+
+		template <int T>
+		hipError_t launch_tile(hipStream_t s, const GemmDesc& d)
+		{
+			if (d.M % T || d.N % T || d.K % BK || d.M <= 0 || d.N <= 0 || d.batch <= 0) return hipErrorInvalidValue;
+			const dim3 grid(d.M / T, d.N / T, d.batch), block(256);
+#define GPLE_GEMM_CASE(ak, bk, ct)                                                           \
+	if (d.a_kmajor == ak && d.b_kmajor == bk && d.c_trans == ct)                              \
+	{                                                                                         \
+		hipLaunchKernelGGL((gemm_f64_kernel<T, T, ak, bk, ct>), grid, block, 0, s, d);        \
+		return hipGetLastError();                                                             \
+	}
+			GPLE_GEMM_CASE(false, false, false)
+			GPLE_GEMM_CASE(false, true, false)
+			GPLE_GEMM_CASE(true, true, false)
+			GPLE_GEMM_CASE(false, false, true)
+			GPLE_GEMM_CASE(false, true, true)
+#undef GPLE_GEMM_CASE
+			return hipErrorInvalidValue;
+		}
+	} // namespace
+
+	hipError_t launch_gemm(hipStream_t s, const GemmDesc& d, int tile)
+	{
+		return tile == 128 ? launch_tile<128>(s, d) : launch_tile<64>(s, d);
+	}
+} // namespace gple

@@ -1,0 +1,131 @@
+// gple_internal.h — shared declarations of the HIP implementation behind include/gple.h (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gple.h"
+
+namespace gple
+{
+	// ---- geometry ------------------------------------------------------------------------------------------
+	// Every N x N matrix of a fit lives in HBM column-major with the training size padded to a multiple of NPAD
+	// (identity on the padded diagonal, zero elsewhere), so that no dense kernel needs edge handling:
+	//   K_pad = [K 0; 0 I]  =>  chol, inverse factor and inverse are the padded versions of the true ones.
+	constexpr int NPAD = 256;   // = N-tile of the predict kernel; multiple of every other tile size
+	constexpr int CHOL_NB = 64; // panel width of the blocked Cholesky / size of the LDS-resident diagonal block
+
+	inline size_t round_up(size_t n, size_t m) { return (n + m - 1) / m * m; }
+
+	// ---- error plumbing ------------------------------------------------------------------------------------
+	struct Ctx;
+	int record_hip_error(Ctx* ctx, hipError_t e, const char* what, int line);
+#define GPLE_HIP(ctx, expr)                                                        \
+	do                                                                             \
+	{                                                                              \
+		hipError_t gple_e_ = (expr);                                               \
+		if (gple_e_ != hipSuccess) return gple::record_hip_error((ctx), gple_e_, #expr, __LINE__); \
+	} while (0)
+#define GPLE_TRY(expr)                        \
+	do                                        \
+	{                                         \
+		int gple_s_ = (expr);                 \
+		if (gple_s_ != GPLE_OK) return gple_s_; \
+	} while (0)
+
+	// ---- device buffer -------------------------------------------------------------------------------------
+	struct DevBuf
+	{
+		void* p = nullptr;
+		size_t bytes = 0;
+		DevBuf() = default;
+		DevBuf(const DevBuf&) = delete;
+		DevBuf& operator=(const DevBuf&) = delete;
+		~DevBuf() { release(); }
+		hipError_t alloc(size_t nbytes)
+		{
+			release();
+			if (nbytes == 0) return hipSuccess;
+			hipError_t e = hipMalloc(&p, nbytes);
+			if (e == hipSuccess) bytes = nbytes;
+			else p = nullptr;
+			return e;
+		}
+		hipError_t ensure(size_t nbytes) { return nbytes <= bytes ? hipSuccess : alloc(nbytes); }
+		void release()
+		{
+			if (p) (void)hipFree(p);
+			p = nullptr;
+			bytes = 0;
+		}
+		double* d() const { return static_cast<double*>(p); }
+	};
+
+	// ---- context -------------------------------------------------------------------------------------------
+	struct Ctx
+	{
+		int device = 0;
+		hipStream_t stream = nullptr;
+		bool owns_stream = false;
+		std::string last_error;
+		std::mutex mu; // guards last_error + scratch (predict calls may come from several host threads)
+		// pinned host block for scalar results
+		double* host_scalars = nullptr;
+		// tracing (gple_ctx_enable_timing): event pairs per gple_timer
+		bool timing = false;
+		hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+		bool ev_pending[3] = {false, false, false};
+		double t_last[3] = {0, 0, 0}, t_total[3] = {0, 0, 0};
+		long t_count[3] = {0, 0, 0};
+	};
+	// record the start / stop event of timer `which` (no-ops unless timing is on); collect after a stream sync
+	void timer_start(Ctx* c, int which);
+	void timer_stop(Ctx* c, int which);
+	void timer_collect(Ctx* c);
+
+	// ---- fp64 MFMA GEMM family (gple_gemm.hip) -------------------------------------------------------------
+	// C(m,n) (+)= alpha * sum_k A(m,k) * B(n,k)    [all sizes multiples of the tile]
+	// Operand layouts: *_kmajor == false: element (r,k) at r + k*ld (r contiguous);  true: at k + r*ld.
+	// c_trans == false: C(m,n) at m + n*ldc;  true: at n + m*ldc.
+	enum KRange
+	{
+		K_FULL = 0,
+		K_GE_N = 1,     // B(n,k) != 0 only for k >= n       -> start at the tile's first n
+		K_LE_M = 2,     // A(m,k) != 0 only for k <= m       -> stop after the tile's last m
+		K_GE_MAX_MN = 3 // A(m,k)!=0 for k>=m and B(n,k)!=0 for k>=n (T^T T)
+	};
+	struct GemmDesc
+	{
+		const double* A;
+		long lda;
+		long strideA; // per batch item
+		const double* B;
+		long ldb;
+		long strideB;
+		double* C;
+		long ldc;
+		long strideC;
+		int M, N, K;
+		int batch;
+		double alpha, beta;
+		int krange;     // KRange
+		int lower_only; // only tiles with m0 + BM > n0 are computed (symmetric / triangular results)
+		bool a_kmajor, b_kmajor, c_trans;
+	};
+	// tile: 64 (64x64 per workgroup) or 128 (128x128 per workgroup)
+	hipError_t launch_gemm(hipStream_t s, const GemmDesc& d, int tile);
+
+	// ---- dense factorisation drivers (gple_chol.hip) -------------------------------------------------------
+	// In-place lower Cholesky of the n x n (n multiple of CHOL_NB) column-major matrix A; the strictly upper part
+	// is zeroed. diag_inv receives inv(L_jj) of every CHOL_NB diagonal block *inside* T (n x n, ldt), i.e. the
+	// diagonal blocks of T = L^-1. info (device int): 0 or 1 + index of the first non-positive pivot.
+	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info);
+	// Completes T = L^-1 (lower) given its diagonal blocks; work: at least n*n/4 doubles.
+	hipError_t trtri_lower_from_diag(hipStream_t s, const double* L, long ldl, double* T, long ldt, int n, double* work);
+	// W = T^T T (full symmetric n x n).
+	hipError_t lauum_full(hipStream_t s, const double* T, long ldt, double* W, long ldw, int n);
+} // namespace gple

@@ -1,0 +1,76 @@
+// gple_kernels.h — launchers of the non-GEMM device kernels (gple_kernels.hip, gple_predict.hip).
+#pragma once
+#include "gple_internal.h"
+
+namespace gple
+{
+	// One squared-exponential kernel  amp * (exp(-((dx*rl0)^2 + (dp*rl1)^2)/2) + n2 * delta).
+	// `l` keeps the lengths for the bit-faithful (division) form used when a Gram matrix is materialised.
+	struct SEParam
+	{
+		double amp, n2;
+		double l0, l1;
+		double rl0, rl1;
+	};
+	// Kernel functions between "typed" points.  The real GP has one type; the complex (widely linear) GP is run as a
+	// real GP on [Re; Im] whose 2N x 2N covariance has blocks  [kR + n/2, kC; kC, kI + n/2]  (DESIGN.md §complex):
+	// p[type_a + type_b] with type 0 = real part, 1 = imaginary part  ->  p[0] = RR, p[1] = RI (correlation), p[2] = II.
+	struct SEParamSet
+	{
+		SEParam p[3];
+	};
+
+	// ---- training side ---------------------------------------------------------------------------------------
+	// ys[i] = s * y[i*stride + offset] for i < N (0 for N <= i < Np), s = 10 / max_i |label_i|, written to *s_out.
+	// complex_abs != 0: |label| is the complex modulus of the (re,im) pair and both halves are produced:
+	// ys[0..Np) = s*re, ys[Np..2Np) = s*im.
+	hipError_t launch_prep_labels(hipStream_t s, const double* y, int stride, int complex_abs, int N, int Np, double* ys,
+		double* s_out);
+	// K_pad (n_total x n_total, ld) of the typed training set: n_total = Np (real) or 2*Np (complex, split at Np);
+	// points Xt (N interleaved); padded rows/cols get the identity.
+	hipError_t launch_gram_train(hipStream_t s, const double* Xt, int N, int Np, int n_total, SEParamSet ps, double* K, long ld);
+	// u = T * ys (lower triangular T, n x n): partial sums then reduction. part: (n/256) * n doubles.
+	hipError_t launch_trmv_lower(hipStream_t s, const double* T, long ldt, int n, const double* ys, double* part, double* u);
+	// v[k] = sum_i T(i,k) u[i],  w[k] = sum_i T(i,k)^2 ; optionally wx[k] = sum_i T(i,k) T(i,k+shift) (complex: diag of Mxy).
+	hipError_t launch_colpass(hipStream_t s, const double* T, long ldt, int n, const double* u, double* v, double* w, int shift,
+		double* wx);
+	// raw sums for the real fit: out[0]=sum (v/w)^2, out[1]=sum v, out[2]=sum x v, out[3]=sum p v, out[4]=sum ys v
+	hipError_t launch_real_fit_sums(hipStream_t s, const double* Xt, const double* ys, const double* v, const double* w, int N,
+		double* out);
+	// out[0] = sum_ij a_i k(x_i,x_j) b_j over i,j < N with the bit-faithful SE kernel p (amp folded in, no noise)
+	hipError_t launch_quadform(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, double* part,
+		double* out);
+
+	// ---- KernelBase / cutoff ----------------------------------------------------------------------------------
+	// p.amp = sf*sf, p.n2 = sn*sn; sf and sn are passed too because the derivative formulas use them unsquared.
+	hipError_t launch_gram_rect(hipStream_t s, const double* L, int R, const double* Rt, int C, int same, SEParam p, double sf, double sn,
+		double* K, double* dK);
+	hipError_t launch_sum(hipStream_t s, const double* part, int n, double* out);
+	hipError_t launch_cutoff(hipStream_t s, const double* pred, int is_complex, const double* var, int M, double* factor);
+
+	// ---- predict ------------------------------------------------------------------------------------------------
+	struct PredictArgs
+	{
+		const double* Xs; // test points, M interleaved pairs
+		int M;            // number of test points
+		int m_rows;       // rows of the (typed) test set: Mh (real) or 2*Mh (complex), Mh = round_up(M, 128)
+		int m_split;      // rows >= m_split are imaginary-part rows (== m_rows for the real GP)
+		const double* Xt; // training points (N valid, readable up to n_split entries)
+		int N;
+		int n_total; // Np or 2*Np
+		int n_split; // Np
+		const double* T;
+		long ldt;
+		const double* v; // n_total weights (K^-1 y in the typed basis)
+		double* q;       // m_rows: || T k*_m ||^2
+		double* mu;      // m_rows: k*_m . v
+		SEParamSet ps;
+	};
+	hipError_t launch_predict_q(hipStream_t s, const PredictArgs& a);
+	// real finish: var = self - q, cutoff, cut = mu*cf/s ; optional labels -> err_out[0] += sum (mu - s t)^2
+	hipError_t launch_predict_finish_real(hipStream_t s, const double* q, const double* mu, int M, double self, const double* s_dev,
+		const double* labels, double* mean, double* var, double* cut, double* err_out);
+	// complex finish: rows [0,M) real part, rows [m_split, m_split+M) imaginary part
+	hipError_t launch_predict_finish_complex(hipStream_t s, const double* q, const double* mu, int M, int m_split, double self,
+		const double* s_dev, const double* labels, double* mean, double* var, double* cut, double* err_out);
+} // namespace gple

@@ -1,0 +1,188 @@
+// gple_predict.hip — fused GP prediction kernel for gfx950 (the dominant kernel of the fit+predict step).
+//
+// Reference hot loop 4 (kernel.cpp:495-518, complex_kernel.cpp:608-642):
+//     mu_i  = K*_i v                      (M x N Gram row times weights)
+//     var_i = k(x*,x*) - K*_i K^-1 K*_i^T   (one N x N GEMV + dot per test point, 2 M N^2 flops)
+// The reference materialises the M x N matrix K* and the explicit inverse.  Here
+//   * K^-1 = T^T T with T = chol(K)^-1 lower triangular, so  K*_i K^-1 K*_i^T = || T K*_i^T ||^2  — a triangular
+//     contraction (M N^2 flops) whose result is a sum of squares (no cancellation inside the quadratic form);
+//   * K* is never written to HBM: every 128 x 16 slab of it is generated straight into LDS (exp on the VALU) and
+//     consumed as the MFMA operand; the only HBM/L2 stream is T (read once per 128-row tile of test points);
+//   * the row norms are accumulated in registers across all N-tiles, the mean is accumulated while the slab for the
+//     last N-tile (which spans every k) is generated.
+// One workgroup = 8 waves (2 x 4) owns 128 test rows and loops over 256-wide N-tiles; K advances 16 per step through a
+// double-buffered LDS stage (A: generated 16 x 128, B: 16 x 256 of T).  v_mfma_f64_16x16x4_f64 with the result rows on
+// n and the result columns (lane & 15) on the test row m, so that the squared row sums stay lane-local.
+//
+// "Typed" rows/columns implement the complex GP as a real GP on [Re; Im] (see gple_kernels.h, SEParamSet).
+#include "gple_kernels.h"
+
+namespace gple
+{
+	typedef double d4 __attribute__((ext_vector_type(4)));
+	typedef double d2 __attribute__((ext_vector_type(2)));
+
+	namespace
+	{
+		constexpr int BM = 128, BN = 256, BK = 16;
+		constexpr int AS = BM + 16, BS = BN + 16;
+		constexpr int NTHREADS = 512;
+
+		__global__ void __launch_bounds__(NTHREADS) predict_q_kernel(const PredictArgs a)
+		{
+			__shared__ __attribute__((aligned(16))) double lds[2 * BK * AS + 2 * BK * BS];
+			double* const As = lds;
+			double* const Bs = lds + 2 * BK * AS;
+
+			const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+			const int fk = lane >> 4, fr = lane & 15;
+			const int m0 = blockIdx.x * BM;
+			// this thread's test point (fixed for the whole kernel); rows beyond M are clamped and never stored
+			const int ml = t & 127, kq = t >> 7;
+			const int gm = m0 + ml;
+			const int type_m = m0 >= a.m_split; // uniform per workgroup (m_split is a multiple of BM)
+			int pidx = type_m ? gm - a.m_split : gm;
+			pidx = pidx < a.M ? pidx : a.M - 1;
+			const double xm = a.Xs[2 * pidx], pm = a.Xs[2 * pidx + 1];
+
+			double rsq[4] = {0.0, 0.0, 0.0, 0.0};
+			double mu_acc = 0.0;
+			const int ntiles = a.n_total / BN;
+
+			// generate the A slab for k-tile k0 into buffer S; accumulate the mean when asked
+			auto gen_a = [&](double* __restrict__ S, int k0, bool with_mean) {
+				const int type_k = k0 >= a.n_split; // uniform per k-tile (n_split is a multiple of BK)
+				const SEParam& p = a.ps.p[type_m + type_k];
+				const double amp = p.amp, n2 = (type_m == type_k) ? p.n2 : 0.0, rl0 = p.rl0, rl1 = p.rl1;
+				const int kbase = k0 + kq * 4;
+#pragma unroll
+				for (int e = 0; e < 4; ++e)
+				{
+					const int k = kbase + e;
+					const int pk = type_k ? k - a.n_split : k;
+					double val = 0.0;
+					if (pk < a.N)
+					{
+						const double xk = a.Xt[2 * pk], pkv = a.Xt[2 * pk + 1];
+						const double d0 = (xm - xk) * rl0, d1 = (pm - pkv) * rl1;
+						const double g = exp(-0.5 * (d0 * d0 + d1 * d1));
+						const double delta = (xm == xk && pm == pkv) ? n2 : 0.0; // delta_kernel: exact equality, kernel.cpp:26
+						val = amp * (g + delta);
+						if (with_mean) mu_acc = fma(val, a.v[k], mu_acc);
+					}
+					S[(kq * 4 + e) * AS + ml] = val;
+				}
+			};
+			d2 breg[4];
+			auto load_b = [&](int n0, int k0) {
+				const double* __restrict__ base = a.T + n0 + static_cast<long>(k0) * a.ldt;
+#pragma unroll
+				for (int q = 0; q < 4; ++q)
+				{
+					const int i = t + NTHREADS * q;
+					const int r2 = (i & 127) * 2, k = i >> 7;
+					breg[q] = *reinterpret_cast<const d2*>(base + r2 + static_cast<long>(k) * a.ldt);
+				}
+			};
+			auto store_b = [&](double* __restrict__ S) {
+#pragma unroll
+				for (int q = 0; q < 4; ++q)
+				{
+					const int i = t + NTHREADS * q;
+					const int r2 = (i & 127) * 2, k = i >> 7;
+					*reinterpret_cast<d2*>(S + k * BS + r2) = breg[q];
+				}
+			};
+
+			for (int jt = 0; jt < ntiles; ++jt)
+			{
+				const int n0 = jt * BN;
+				const int nk = (n0 + BN) / BK; // T(n,k) = 0 for k > n: k-tiles beyond the N-tile's last column are skipped
+				const bool with_mean = jt == ntiles - 1;
+				d4 acc[4][4];
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+#pragma unroll
+					for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+				__syncthreads(); // the previous tile's last compute is done before the stage is refilled
+				gen_a(As, 0, with_mean);
+				load_b(n0, 0);
+				store_b(Bs);
+				__syncthreads();
+				const int wave_nmax = n0 + wn * 64 + 63;
+				for (int it = 0; it < nk; ++it)
+				{
+					const int cur = it & 1, k0 = it * BK;
+					if (it + 1 < nk) load_b(n0, k0 + BK);
+					if (wave_nmax >= k0) // wave-uniform: this wave's 64 columns are not entirely above the diagonal
+					{
+						const double* __restrict__ pa = As + cur * BK * AS + wm * 64 + fr;
+						const double* __restrict__ pb = Bs + cur * BK * BS + wn * 64 + fr;
+#pragma unroll
+						for (int kk = 0; kk < BK; kk += 4)
+						{
+							double af[4], bf[4];
+#pragma unroll
+							for (int i = 0; i < 4; ++i) af[i] = pa[(kk + fk) * AS + i * 16];
+#pragma unroll
+							for (int j = 0; j < 4; ++j) bf[j] = pb[(kk + fk) * BS + j * 16];
+#pragma unroll
+							for (int i = 0; i < 4; ++i)
+#pragma unroll
+								for (int j = 0; j < 4; ++j)
+									acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+						}
+					}
+					if (it + 1 < nk)
+					{
+						gen_a(As + (cur ^ 1) * BK * AS, k0 + BK, with_mean);
+						store_b(Bs + (cur ^ 1) * BK * BS);
+					}
+					__syncthreads();
+				}
+				// result element [n = 16 j + fk + 4 r][m = 16 i + fr]: the row index m is lane-local
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) rsq[i] = fma(acc[i][j][r], acc[i][j][r], rsq[i]);
+			}
+
+			// reduce over the four lane groups (same fr), then over the four n-waves and the four k-quarters via LDS
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+			{
+				rsq[i] += __shfl_xor(rsq[i], 16);
+				rsq[i] += __shfl_xor(rsq[i], 32);
+			}
+			__syncthreads();
+			double* const red_q = lds;            // [4 (wn)][128]
+			double* const red_mu = lds + 4 * 128; // [4 (kq)][128]
+			if (lane < 16)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) red_q[wn * 128 + wm * 64 + i * 16 + lane] = rsq[i];
+			red_mu[kq * 128 + ml] = mu_acc;
+			__syncthreads();
+			if (t < 128)
+			{
+				const int row = m0 + t;
+				const int prow = type_m ? row - a.m_split : row;
+				if (prow < a.M)
+				{
+					a.q[row] = (red_q[t] + red_q[128 + t]) + (red_q[256 + t] + red_q[384 + t]);
+					a.mu[row] = (red_mu[t] + red_mu[128 + t]) + (red_mu[256 + t] + red_mu[384 + t]);
+				}
+			}
+		}
+	} // namespace
+
+	hipError_t launch_predict_q(hipStream_t s, const PredictArgs& a)
+	{
+		if (a.M <= 0) return hipSuccess;
+		if (a.m_rows % BM || a.n_total % BN || a.m_split % BM || a.n_split % BN) return hipErrorInvalidValue;
+		hipLaunchKernelGGL(predict_q_kernel, dim3(a.m_rows / BM), dim3(NTHREADS), 0, s, a);
+		return hipGetLastError();
+	}
+} // namespace gple

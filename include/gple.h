@@ -110,6 +110,18 @@ const char* gple_status_string(int status);
 /* Last HIP error text seen by this context (empty string when none). */
 const char* gple_ctx_last_error(const gple_ctx* ctx);
 
+/* ---- tracing --------------------------------------------------------------------------------------- */
+/* The reference only logs wall-clock seconds per output (output.cpp:246-248). With timing enabled the library
+ * brackets its phases with HIP events on the context's stream; read them back after a call has completed. */
+typedef enum gple_timer {
+	GPLE_TIMER_FIT = 0,            /* whole *_fit_create call (device side)                 */
+	GPLE_TIMER_PREDICT = 1,        /* whole *_predict call (device side)                    */
+	GPLE_TIMER_PREDICT_KERNEL = 2  /* the fused variance/mean kernel of *_predict alone     */
+} gple_timer;
+int gple_ctx_enable_timing(gple_ctx* ctx, int on);
+/* last: milliseconds of the most recent call; total / count: accumulated since enable (any may be NULL). */
+int gple_ctx_get_timing(gple_ctx* ctx, gple_timer which, double* last_ms, double* total_ms, long* count);
+
 /* ---- KernelBase (kernel.h:29-106, kernel.cpp:8-242) ---------------------------------------------- */
 /* K = sf^2 (G + sn^2 delta) for theta = (sf, lx, lp, sn), left 2 x R, right 2 x C, K is R x C column-major.
  * same_features != 0 reproduces the `LeftFeature.data() == RightFeature.data()` branch (identity delta,

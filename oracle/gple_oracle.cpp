@@ -1146,6 +1146,16 @@ namespace
 // -------------------------------------------------------------------------------------------------------------
 extern "C"
 {
+	int oracle_set_num_threads(int n)
+	{
+#ifdef _OPENMP
+		if (n > 0) omp_set_num_threads(n);
+#else
+		(void)n;
+#endif
+		return GPLE_OK;
+	}
+
 	int oracle_num_threads(void)
 	{
 #ifdef _OPENMP

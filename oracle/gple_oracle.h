@@ -53,6 +53,9 @@ int oracle_nlml_predict(const double x[4], const double* X, const double* y, siz
 
 /* number of OpenMP threads the oracle will use (for the cpu_baseline "cores" field) */
 int oracle_num_threads(void);
+/* the OpenMP default (all online CPUs) oversubscribes a cgroup-limited box badly: oracle/binding.py sets this to the
+ * CPU share actually available */
+int oracle_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,159 @@
+"""GPU (MI355X): the HIP path, called through the C-ABI, against the 50-digit fixtures, the CPU oracle and
+size-independent identities at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+
+from gaussian_process_liouville_equation_amd import _capi as c
+from tests import parity
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", parity.REAL_FIXTURES)
+def test_real_fixture(gpu, name):
+    parity.check_real_case(gpu, load_golden(name), deriv=False)
+
+
+@pytest.mark.parametrize("name,tol", parity.COMPLEX_FIXTURES)
+def test_complex_fixture(gpu, name, tol):
+    parity.check_complex_case(gpu, load_golden(name), deriv=False, tol=tol)
+
+
+@pytest.mark.parametrize("name", parity.REAL_FIXTURES)
+def test_gram_and_derivatives_ulp(gpu, oracle, name):
+    """KernelBase (kernel.cpp:8-242): Gram entries within (4+|a|) eps of the correctly rounded value, derivative
+    matrices likewise; rectangular branch with exact-equality delta against the oracle."""
+    g = load_golden(name)
+    K, dK = gpu.real_gram(g["theta"], g["X"], g["X"], True, True)
+    parity.check_gram_ulp(K, g["K"], g["theta"], g["X"])
+    for ip in range(4):
+        parity.check_gram_ulp(dK[ip], g["dK"][ip], g["theta"], g["X"])
+    Kr, dKr = gpu.real_gram(g["theta"], g["Xs"], g["X"], False, True)
+    Ko, dKo = oracle.real_gram(g["theta"], g["Xs"], g["X"], False, True)
+    parity.check_gram_ulp(Kr, Ko, g["theta"], g["Xs"], g["X"])
+    for ip in range(4):
+        parity.check_gram_ulp(dKr[ip], dKo[ip], g["theta"], g["Xs"], g["X"])
+
+
+def test_cutoff_factor_classes(gpu, oracle):
+    """kernel.h:301-332: exact 0 / 1 classes and the cubic in between, real and complex."""
+    var = np.array([1.0, 1.0, 1.0, 1.0, 4.0, 0.25, 1.0])
+    pred = np.array([0.5, 1.0, 1.5, 2.0, 3.0, -0.9, -2.5])
+    f = gpu.cutoff_factor(pred, var)
+    assert np.array_equal(f[[0, 1, 3, 6]], [0.0, 0.0, 1.0, 1.0])
+    assert np.abs(f - oracle.cutoff_factor(pred, var)).max() <= 4 * parity.EPS
+    predc = pred * np.exp(0.7j)
+    assert np.abs(gpu.cutoff_factor(predc, var) - oracle.cutoff_factor(predc, var)).max() <= 1e-15
+
+
+@pytest.mark.parametrize("N,M,seed", [(1, 5, 1), (63, 129, 2), (257, 300, 3), (300, 1000, 4)])
+def test_real_against_oracle_ragged_sizes(gpu, oracle, N, M, seed):
+    """sizes that are not multiples of any tile (padding paths), theta = the reference's initial parameters"""
+    X, y, Xs = parity.synthetic_real(N, M, seed)
+    theta = [1.0, 0.7086, 0.7056, 1e-2]
+    fg, fo = gpu.real_fit(theta, X, y, 3), oracle.real_fit(theta, X, y, 3)
+    assert fg.scalars["info"] == 0
+    for k in ("population", "purity", "magnitude"):
+        assert abs(fg.scalars[k] - fo.scalars[k]) <= 1e-8 * abs(fo.scalars[k]), k
+    assert abs(fg.scalars["error"] - fo.scalars["error"]) <= 1e-6 * abs(fo.scalars["error"])
+    pg, po = gpu.real_predict(fg, Xs), oracle.real_predict(fo, Xs)
+    scale = np.abs(po["prediction"]).max()
+    assert np.abs(pg["prediction"] - po["prediction"]).max() <= 1e-10 * scale  # mean abs 1e-10 * s^-1 max|y|
+    assert np.abs(pg["variance"] - po["variance"]).max() <= 1e-9                # variance abs 1e-9 * sf^2
+    assert np.abs(pg["cutoff"] - po["cutoff"]).max() <= 1e-9 * scale / fo.scalars["rescale_factor"]
+
+
+def test_empty_and_single_test_sets(gpu):
+    X, y, Xs = parity.synthetic_real(40, 1, 9)
+    fit = gpu.real_fit([1.0, 0.7, 0.7, 0.1], X, y, 3)
+    p0 = gpu.real_predict(fit, np.zeros((0, 2)))
+    assert p0["prediction"].size == 0 and np.isnan(p0["error"])
+    p1 = gpu.real_predict(fit, Xs)
+    assert p1["prediction"].shape == (1,) and np.isfinite(p1["variance"][0])
+
+
+def test_prediction_at_training_points_uses_delta_kernel(gpu, oracle):
+    """test point == training point: the noise delta enters K* and k** (kernel.cpp:26, 512) so var = k** - k W k^T"""
+    X, y, _ = parity.synthetic_real(50, 1, 10)
+    theta = [1.2, 0.7, 0.6, 0.3]
+    fg, fo = gpu.real_fit(theta, X, y, 1), oracle.real_fit(theta, X, y, 1)
+    pg, po = gpu.real_predict(fg, X), oracle.real_predict(fo, X)
+    assert np.abs(pg["variance"] - po["variance"]).max() <= 1e-11
+    assert np.abs(pg["prediction"] - po["prediction"]).max() <= 1e-11 * np.abs(po["prediction"]).max()
+    # K v = y  =>  the (uncut) prediction at the training points reproduces the rescaled labels
+    assert np.abs(pg["prediction"] - fg.get(c.R_LABEL)).max() <= 1e-10 * 10.0
+
+
+def test_non_spd_input_propagates_nan_and_sets_info(gpu):
+    """duplicate points with zero noise make K singular: no abort, info > 0 / non-finite outputs (reference: NaN/Inf
+    flow on and are clamped by make_normal, opt.cpp:420-431)."""
+    X, y, Xs = parity.synthetic_real(32, 8, 11)
+    X[5] = X[4]
+    fit = gpu.real_fit([1.0, 0.7, 0.7, 0.0], X, y, 3)
+    p = gpu.real_predict(fit, Xs)
+    assert fit.scalars["info"] > 0 or not np.isfinite(fit.scalars["error"]) or not np.all(np.isfinite(p["variance"]))
+
+
+@pytest.mark.parametrize("N,M,seed", [(40, 64, 21), (200, 333, 22)])
+def test_complex_against_oracle(gpu, oracle, N, M, seed):
+    X, yr, Xs = parity.synthetic_real(N, M, seed)
+    y = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0))
+    theta = [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05]
+    fg, fo = gpu.complex_fit(theta, X, y, 3), oracle.complex_fit(theta, X, y, 3)
+    assert fg.scalars["info"] == 0
+    for k in ("error", "purity", "magnitude"):
+        assert abs(fg.scalars[k] - fo.scalars[k]) <= 1e-7 * abs(fo.scalars[k]), k
+    pg, po = gpu.complex_predict(fg, Xs), oracle.complex_predict(fo, Xs)
+    scale = np.abs(po["prediction"]).max()
+    assert np.abs(pg["prediction"] - po["prediction"]).max() <= 1e-9 * scale
+    assert np.abs(pg["variance"] - po["variance"]).max() <= 1e-8
+    assert np.abs(pg["cutoff"] - po["cutoff"]).max() <= 1e-8 * scale / fo.scalars["rescale_factor"]
+    assert parity.rel(fg.get(c.C_UPPER_LEFT), fo.get(c.C_UPPER_LEFT)) <= 1e-8
+    assert parity.rel(fg.get(c.C_LOWER_LEFT), fo.get(c.C_LOWER_LEFT)) <= 1e-8
+
+
+def test_full_size_c2_identities(gpu):
+    """BASELINE C2 (N=1024, 256x256 grid): size-independent properties instead of an element-wise oracle run:
+    K W = I residual, K v = y residual, variance in [-1e-8, k**], mean at far-away grid points -> 0, cut <= mean."""
+    N, G = 1024, 256
+    X, y, _ = parity.synthetic_real(N, 1, 20240607 + 1)
+    theta = [1.0, 0.7086, 0.7056, 1e-2]
+    fit = gpu.real_fit(theta, X, y, 3)
+    assert fit.scalars["info"] == 0
+    K, W, v, ys = fit.get(c.R_KERNEL), fit.get(c.R_INVERSE), fit.get(c.R_INVLBL), fit.get(c.R_LABEL)
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    assert n1(K @ W - np.eye(N)) <= 50 * N * parity.EPS * n1(K) * n1(W)
+    assert np.abs(K @ v - ys).max() <= 50 * N * parity.EPS * (n1(K) * np.abs(v).max() + np.abs(ys).max())
+    dx = 40.0 / G
+    xs = -20.0 + dx * np.arange(G)
+    ps = (14.112 - np.pi / (2 * dx)) + (np.pi / dx / G) * np.arange(G)
+    gx, gp = np.meshgrid(xs, ps, indexing="ij")  # index = ix * G + ip (input.cpp:37-70)
+    p = gpu.real_predict(fit, np.stack([gx.ravel(), gp.ravel()], 1))
+    kss = theta[0] ** 2 * (1 + theta[3] ** 2)
+    assert p["variance"].min() >= -1e-8 and p["variance"].max() <= kss + 1e-12
+    far = (np.abs(gx.ravel() + 10) > 8)
+    assert np.abs(p["prediction"][far]).max() <= 1e-9 and np.abs(p["variance"][far] - kss).max() <= 1e-9
+    assert np.all(np.abs(p["cutoff"]) <= np.abs(p["prediction"]) / fit.scalars["rescale_factor"] + 1e-15)
+    # analytic population == grid quadrature of the uncut mean (kernel.cpp:286-297)
+    quad = p["prediction"].sum() * dx * (np.pi / dx / G) / fit.scalars["rescale_factor"]
+    assert abs(quad - fit.scalars["population"]) <= 1e-6 * abs(fit.scalars["population"])
+
+
+def test_device_pointer_io_matches_host_io(gpu):
+    """GPLE_IO_DEVICE: device-resident inputs/outputs (torch tensors as plain device memory) give the same bits."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    X, y, Xs = parity.synthetic_real(200, 500, 31)
+    theta = np.array([1.0, 0.7086, 0.7056, 1e-2])
+    fit = gpu.real_fit(theta, X, y, 3)
+    ph = gpu.real_predict(fit, Xs)
+    dXs = torch.from_numpy(Xs).cuda()
+    out = torch.empty(3, len(Xs), dtype=torch.float64, device="cuda")
+    dp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))
+    ps = c.PredictScalars()
+    st = gpu.lib.gple_real_predict(gpu.ctx, fit.handle, dp(dXs), len(Xs), c.IO_DEVICE, None, dp(out[0]), dp(out[1]), dp(out[2]), C.byref(ps))
+    assert st == 0
+    gpu.synchronize()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[0], ph["prediction"]) and np.array_equal(o[1], ph["variance"]) and np.array_equal(o[2], ph["cutoff"])
