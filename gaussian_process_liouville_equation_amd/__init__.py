@@ -18,6 +18,13 @@ def load_library():
     """dlopen csrc/libgple_hip.so (built by __graft_entry__.build() / `make -C .../csrc`). Fails loudly."""
     global _lib
     if _lib is None:
+        # PyTorch ships its own libamdhip64; whichever HIP runtime is mapped first serves the whole process, and torch
+        # cannot see the GPU if the system runtime got in before it.  Import torch first when it is installed so the
+        # library, torch tensors (device memory) and torch.distributed (RCCL) share one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found: the HIP extension is not built "
                               "(run `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")

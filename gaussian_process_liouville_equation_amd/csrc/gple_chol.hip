@@ -16,56 +16,68 @@ namespace gple
 	namespace
 	{
 		constexpr int NB = CHOL_NB; // 64
-		constexpr int LD = NB + 1;  // LDS leading dimension (odd: conflict-free column and row walks)
 
-		// One workgroup factors the NB x NB diagonal block in LDS and also inverts the factor.
+		// One wave factors the NB x NB diagonal block and inverts the factor, register-resident:
+		//   Cholesky: lane i owns row i of the block (64 doubles in VGPRs); column k is scaled lane-locally, published
+		//             to LDS and broadcast back for the rank-1 update of the lane's row (fully unrolled, so every row
+		//             element stays a named register);
+		//   inverse : lane j owns column j of X = L^-1 and runs its own forward substitution; row i of L is an LDS
+		//             broadcast.
+		// ~2 x 2016 dependent FMAs with LDS broadcasts in between instead of 128 block-wide barrier rounds.
 		// A (global, column-major, lda): in = SPD block (lower used), out = L (lower), strictly upper zeroed.
 		// Tinv (global, ldt): out = L^-1 (lower), strictly upper zeroed.
-		__global__ void __launch_bounds__(256) potrf_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Tinv, long ldt,
+		constexpr int LR = NB + 2; // LDS row stride (doubles): 16-byte aligned rows, rows 4 banks apart
+		__global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Tinv, long ldt,
 			int* __restrict__ info, int j0)
 		{
-			__shared__ double L[NB * LD];
-			__shared__ double X[NB * LD];
-			const int t = threadIdx.x, i = t & 63, jg = t >> 6;
-			for (int j = jg; j < NB; j += 4)
+			__shared__ __attribute__((aligned(16))) double col[NB];
+			__shared__ __attribute__((aligned(16))) double Ls[NB * LR];
+			const int i = threadIdx.x;
+			double a[NB];
+#pragma unroll
+			for (int j = 0; j < NB; ++j) a[j] = A[i + static_cast<long>(j) * lda]; // coalesced: lanes = consecutive rows
+			bool bad = false;
+#pragma unroll
+			for (int k = 0; k < NB; ++k)
 			{
-				L[i + j * LD] = (i >= j) ? A[i + static_cast<long>(j) * lda] : 0.0;
-				X[i + j * LD] = (i == j) ? 1.0 : 0.0;
+				const double d = __shfl(a[k], k);
+				bad = bad || !(d > 0.0);
+				if (bad && i == 0) atomicCAS(info, 0, j0 + k + 1); // first offending column wins (info starts at 0)
+				const double sd = sqrt(d);
+				const double l = (i == k) ? sd : a[k] / sd;
+				a[k] = (i >= k) ? l : 0.0;
+				col[i] = l;
+				__syncthreads();
+#pragma unroll
+				for (int j = k + 1; j < NB; ++j) a[j] = fma(-l, col[j], a[j]);
+				__syncthreads();
+			}
+#pragma unroll
+			for (int j = 0; j < NB; ++j)
+			{
+				A[i + static_cast<long>(j) * lda] = a[j];
+				Ls[i * LR + j] = a[j];
 			}
 			__syncthreads();
-			for (int k = 0; k < NB; ++k)
+			// lane j: column j of X.  x[i] = (delta_ij - sum_{k=j}^{i-1} L(i,k) x[k]) / L(i,i); entries above the diagonal are 0,
+			// so the sum may start at k = 0 for every lane.
+			double x[NB];
+			const int j = threadIdx.x;
+#pragma unroll
+			for (int r = 0; r < NB; ++r)
 			{
-				const double d = L[k + k * LD];
-				const double sd = sqrt(d);
-				double lik = 0.0;
-				if (t < NB && t >= k) lik = (t == k) ? sd : L[t + k * LD] / sd;
-				if (t == 0 && !(d > 0.0)) atomicCAS(info, 0, j0 + k + 1);
-				__syncthreads();
-				if (t < NB && t >= k) L[t + k * LD] = lik;
-				__syncthreads();
-				const double li = L[i + k * LD];
-				for (int j = k + 1 + jg; j < NB; j += 4)
-					if (i >= j) L[i + j * LD] -= li * L[j + k * LD];
-				__syncthreads();
+				double s = (r == j) ? 1.0 : 0.0;
+#pragma unroll
+				for (int k = 0; k < r; ++k) s = fma(-Ls[r * LR + k], x[k], s);
+				x[r] = (r >= j) ? s / Ls[r * LR + r] : 0.0;
 			}
-			// X = L^-1 by forward substitution on all columns at once
-			for (int k = 0; k < NB; ++k)
-			{
-				const double dk = L[k + k * LD];
-				if (t <= k) X[k + t * LD] /= dk;
-				__syncthreads();
-				if (i > k)
-				{
-					const double lik = L[i + k * LD];
-					for (int j = jg; j <= k; j += 4) X[i + j * LD] -= lik * X[k + j * LD];
-				}
-				__syncthreads();
-			}
-			for (int j = jg; j < NB; j += 4)
-			{
-				A[i + static_cast<long>(j) * lda] = L[i + j * LD];
-				Tinv[i + static_cast<long>(j) * ldt] = X[i + j * LD];
-			}
+			__syncthreads();
+			// transpose through LDS for coalesced stores: Ls[c][r] <- X(r, c)
+#pragma unroll
+			for (int r = 0; r < NB; ++r) Ls[j * LR + r] = x[r];
+			__syncthreads();
+#pragma unroll
+			for (int c = 0; c < NB; ++c) Tinv[i + static_cast<long>(c) * ldt] = Ls[c * LR + i];
 		}
 
 		// upper(i<j) = lower(j,i) for a full symmetric result
@@ -97,7 +109,7 @@ namespace gple
 		if (n % NB) return hipErrorInvalidValue;
 		for (int j0 = 0; j0 < n; j0 += NB)
 		{
-			hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, s, A + j0 + static_cast<long>(j0) * lda, lda,
+			hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, A + j0 + static_cast<long>(j0) * lda, lda,
 				T + j0 + static_cast<long>(j0) * ldt, ldt, info, j0);
 			const int m = n - j0 - NB;
 			if (m <= 0) break;

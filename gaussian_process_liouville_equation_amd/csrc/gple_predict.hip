@@ -10,11 +10,16 @@
 //     consumed as the MFMA operand; the only HBM/L2 stream is T (read once per 128-row tile of test points);
 //   * the row norms are accumulated in registers across all N-tiles, the mean is accumulated while the slab for the
 //     last N-tile (which spans every k) is generated.
-// One workgroup = 8 waves (2 x 4) owns 128 test rows and loops over 256-wide N-tiles; K advances 16 per step through a
-// double-buffered LDS stage (A: generated 16 x 128, B: 16 x 256 of T).  v_mfma_f64_16x16x4_f64 with the result rows on
-// n and the result columns (lane & 15) on the test row m, so that the squared row sums stay lane-local.
+// One workgroup = 8 waves owns 128 test rows and loops over 256-wide N-tiles; K advances 16 per step through a
+// double-buffered LDS stage (A: generated 16 x 128, B: 16 x 256 of T).  Each wave owns 16 rows x all 256 columns
+// (16 accumulator tiles): every wave then sees the same triangular structure, so the all-zero 16 x 16 blocks of T
+// (k > n) are skipped by all waves alike and nobody idles behind the per-step barrier (a 2 x 4 wave grid left whole
+// SIMDs idle in the diagonal region: measured 51 % -> see profiles/).  v_mfma_f64_16x16x4_f64 with the result rows
+// on n and the result columns (lane & 15) on the test row m, so that the squared row sums stay lane-local.
 //
 // "Typed" rows/columns implement the complex GP as a real GP on [Re; Im] (see gple_kernels.h, SEParamSet).
+#include <type_traits>
+
 #include "gple_kernels.h"
 
 namespace gple
@@ -34,18 +39,20 @@ namespace gple
 			double* const As = lds;
 			double* const Bs = lds + 2 * BK * AS;
 
-			const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
 			const int fk = lane >> 4, fr = lane & 15;
 			const int m0 = blockIdx.x * BM;
 			// this thread's test point (fixed for the whole kernel); rows beyond M are clamped and never stored
-			const int ml = t & 127, kq = t >> 7;
+			// kq is the same for all lanes of a wave; readfirstlane tells the compiler, so the training point and weight
+			// loads of gen_a become scalar (SMEM) loads
+			const int ml = t & 127, kq = __builtin_amdgcn_readfirstlane(t >> 7);
 			const int gm = m0 + ml;
 			const int type_m = m0 >= a.m_split; // uniform per workgroup (m_split is a multiple of BM)
 			int pidx = type_m ? gm - a.m_split : gm;
 			pidx = pidx < a.M ? pidx : a.M - 1;
 			const double xm = a.Xs[2 * pidx], pm = a.Xs[2 * pidx + 1];
 
-			double rsq[4] = {0.0, 0.0, 0.0, 0.0};
+			double rsq = 0.0;
 			double mu_acc = 0.0;
 			const int ntiles = a.n_total / BN;
 
@@ -55,7 +62,7 @@ namespace gple
 				const SEParam& p = a.ps.p[type_m + type_k];
 				const double amp = p.amp, n2 = (type_m == type_k) ? p.n2 : 0.0, rl0 = p.rl0, rl1 = p.rl1;
 				const int kbase = k0 + kq * 4;
-#pragma unroll
+#pragma unroll 2
 				for (int e = 0; e < 4; ++e)
 				{
 					const int k = kbase + e;
@@ -99,39 +106,36 @@ namespace gple
 				const int n0 = jt * BN;
 				const int nk = (n0 + BN) / BK; // T(n,k) = 0 for k > n: k-tiles beyond the N-tile's last column are skipped
 				const bool with_mean = jt == ntiles - 1;
-				d4 acc[4][4];
+				d4 acc[16];
 #pragma unroll
-				for (int i = 0; i < 4; ++i)
-#pragma unroll
-					for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+				for (int j = 0; j < 16; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
 
 				__syncthreads(); // the previous tile's last compute is done before the stage is refilled
 				gen_a(As, 0, with_mean);
 				load_b(n0, 0);
 				store_b(Bs);
 				__syncthreads();
-				const int wave_nmax = n0 + wn * 64 + 63;
-				for (int it = 0; it < nk; ++it)
-				{
+				// One k-step: MFMAs of slab `it` against the column blocks j >= JMIN, then stage slab it + 1.
+				// JMIN is a compile-time constant per loop: any branch that merges around the accumulators makes hipcc spill
+				// hundreds of VGPRs, so the triangular skipping is expressed as four consecutive loops instead.
+				auto kstep = [&](auto jmin_tag, int it) {
+					constexpr int JMIN = decltype(jmin_tag)::value;
 					const int cur = it & 1, k0 = it * BK;
 					if (it + 1 < nk) load_b(n0, k0 + BK);
-					if (wave_nmax >= k0) // wave-uniform: this wave's 64 columns are not entirely above the diagonal
+					const double* __restrict__ pa = As + cur * BK * AS + w * 16 + fr;
+					const double* __restrict__ pb = Bs + cur * BK * BS + fr;
+#pragma unroll
+					for (int kk = 0; kk < BK; kk += 4)
 					{
-						const double* __restrict__ pa = As + cur * BK * AS + wm * 64 + fr;
-						const double* __restrict__ pb = Bs + cur * BK * BS + wn * 64 + fr;
+						const double af = pa[(kk + fk) * AS];
 #pragma unroll
-						for (int kk = 0; kk < BK; kk += 4)
+						for (int h = JMIN; h < 16; h += 4)
 						{
-							double af[4], bf[4];
+							double bf[4];
 #pragma unroll
-							for (int i = 0; i < 4; ++i) af[i] = pa[(kk + fk) * AS + i * 16];
+							for (int j = 0; j < 4; ++j) bf[j] = pb[(kk + fk) * BS + (h + j) * 16];
 #pragma unroll
-							for (int j = 0; j < 4; ++j) bf[j] = pb[(kk + fk) * BS + j * 16];
-#pragma unroll
-							for (int i = 0; i < 4; ++i)
-#pragma unroll
-								for (int j = 0; j < 4; ++j)
-									acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+							for (int j = 0; j < 4; ++j) acc[h + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af, acc[h + j], 0, 0, 0);
 						}
 					}
 					if (it + 1 < nk)
@@ -140,29 +144,29 @@ namespace gple
 						store_b(Bs + (cur ^ 1) * BK * BS);
 					}
 					__syncthreads();
-				}
-				// result element [n = 16 j + fk + 4 r][m = 16 i + fr]: the row index m is lane-local
+				};
+				// k-steps below the diagonal N-tile and its first 64 columns see every column block; afterwards the column
+				// blocks left of the current k (T(n,k) = 0 for k > n) drop out, 64 columns at a time
+				const int nd = n0 / BK;
+				int it = 0;
+				for (; it < nd + 4; ++it) kstep(std::integral_constant<int, 0>{}, it);
+				for (; it < nd + 8; ++it) kstep(std::integral_constant<int, 4>{}, it);
+				for (; it < nd + 12; ++it) kstep(std::integral_constant<int, 8>{}, it);
+				for (; it < nd + 16; ++it) kstep(std::integral_constant<int, 12>{}, it);
+				// result element [n = 16 j + fk + 4 r][m = 16 w + fr]: the row index m is lane-local
 #pragma unroll
-				for (int i = 0; i < 4; ++i)
+				for (int j = 0; j < 16; ++j)
 #pragma unroll
-					for (int j = 0; j < 4; ++j)
-#pragma unroll
-						for (int r = 0; r < 4; ++r) rsq[i] = fma(acc[i][j][r], acc[i][j][r], rsq[i]);
+					for (int r = 0; r < 4; ++r) rsq = fma(acc[j][r], acc[j][r], rsq);
 			}
 
-			// reduce over the four lane groups (same fr), then over the four n-waves and the four k-quarters via LDS
-#pragma unroll
-			for (int i = 0; i < 4; ++i)
-			{
-				rsq[i] += __shfl_xor(rsq[i], 16);
-				rsq[i] += __shfl_xor(rsq[i], 32);
-			}
+			// reduce over the four lane groups (same fr); the four k-quarters of the mean go through LDS
+			rsq += __shfl_xor(rsq, 16);
+			rsq += __shfl_xor(rsq, 32);
 			__syncthreads();
-			double* const red_q = lds;            // [4 (wn)][128]
-			double* const red_mu = lds + 4 * 128; // [4 (kq)][128]
-			if (lane < 16)
-#pragma unroll
-				for (int i = 0; i < 4; ++i) red_q[wn * 128 + wm * 64 + i * 16 + lane] = rsq[i];
+			double* const red_q = lds;        // [128]
+			double* const red_mu = lds + 128; // [4 (kq)][128]
+			if (lane < 16) red_q[w * 16 + lane] = rsq;
 			red_mu[kq * 128 + ml] = mu_acc;
 			__syncthreads();
 			if (t < 128)
@@ -171,7 +175,7 @@ namespace gple
 				const int prow = type_m ? row - a.m_split : row;
 				if (prow < a.M)
 				{
-					a.q[row] = (red_q[t] + red_q[128 + t]) + (red_q[256 + t] + red_q[384 + t]);
+					a.q[row] = red_q[t];
 					a.mu[row] = (red_mu[t] + red_mu[128 + t]) + (red_mu[256 + t] + red_mu[384 + t]);
 				}
 			}
