@@ -42,9 +42,40 @@ namespace gple
 			c->ev_pending[which] = true;
 		}
 	}
+	void chunk_timer_start(Ctx* c)
+	{
+		if (!c->timing) return;
+		if (static_cast<size_t>(2 * c->chunk_ev_used + 1) >= c->chunk_ev.size())
+		{
+			hipEvent_t e0 = nullptr, e1 = nullptr;
+			if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+			c->chunk_ev.push_back(e0);
+			c->chunk_ev.push_back(e1);
+		}
+		(void)hipEventRecord(c->chunk_ev[2 * c->chunk_ev_used], c->stream);
+	}
+	void chunk_timer_stop(Ctx* c)
+	{
+		if (!c->timing || static_cast<size_t>(2 * c->chunk_ev_used + 1) >= c->chunk_ev.size()) return;
+		(void)hipEventRecord(c->chunk_ev[2 * c->chunk_ev_used + 1], c->stream);
+		c->chunk_ev_used += 1;
+	}
 	void timer_collect(Ctx* c)
 	{
 		if (!c->timing) return;
+		if (c->chunk_ev_used > 0)
+		{
+			double sum = 0.0;
+			for (int i = 0; i < c->chunk_ev_used; ++i)
+			{
+				float ms = 0.f;
+				if (hipEventElapsedTime(&ms, c->chunk_ev[2 * i], c->chunk_ev[2 * i + 1]) == hipSuccess) sum += ms;
+			}
+			c->t_last[GPLE_TIMER_PREDICT_KERNEL] = sum;
+			c->t_total[GPLE_TIMER_PREDICT_KERNEL] += sum;
+			c->t_count[GPLE_TIMER_PREDICT_KERNEL] += c->chunk_ev_used; // per rownorm_kernel launch
+			c->chunk_ev_used = 0;
+		}
 		for (int w = 0; w < 3; ++w)
 			if (c->ev_pending[w])
 			{
@@ -396,6 +427,7 @@ extern "C"
 		if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
 		for (hipEvent_t e : ctx->ev)
 			if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : ctx->chunk_ev) (void)hipEventDestroy(e);
 		if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
 		delete ctx;
 		return GPLE_OK;
@@ -417,6 +449,7 @@ extern "C"
 			for (hipEvent_t& e : ctx->ev) GPLE_HIP(ctx, hipEventCreate(&e));
 		ctx->timing = on != 0;
 		for (int w = 0; w < 3; ++w) ctx->t_last[w] = ctx->t_total[w] = 0.0, ctx->t_count[w] = 0, ctx->ev_pending[w] = false;
+		ctx->chunk_ev_used = 0;
 		return GPLE_OK;
 	}
 	int gple_ctx_get_timing(gple_ctx* ctx, gple_timer which, double* last_ms, double* total_ms, long* count)
@@ -640,9 +673,10 @@ extern "C"
 		a.Xs = xs_dev, a.M = Mi, a.m_rows = m_rows, a.m_split = cplx ? Mh : m_rows;
 		a.Xt = f->Xt, a.N = f->N, a.n_total = f->n_total, a.n_split = cplx ? f->Np : f->n_total;
 		a.T = f->T, a.ldt = f->n_total, a.v = f->v, a.q = q.p, a.mu = mu.p, a.ps = f->ps;
-		timer_start(ctx, GPLE_TIMER_PREDICT_KERNEL);
-		GPLE_HIP(ctx, launch_predict_q(st, a));
-		timer_stop(ctx, GPLE_TIMER_PREDICT_KERNEL);
+		int chunk_rows = 0;
+		Scratch kstar(ctx);
+		GPLE_HIP(ctx, kstar.get(predict_scratch_doubles(a, &chunk_rows)));
+		GPLE_HIP(ctx, launch_predict_q(ctx, st, a, kstar.p, chunk_rows));
 		const double* lab_dev = labels;
 		if (labels && !dev)
 		{

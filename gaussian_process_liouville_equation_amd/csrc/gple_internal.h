@@ -81,7 +81,12 @@ namespace gple
 		bool ev_pending[3] = {false, false, false};
 		double t_last[3] = {0, 0, 0}, t_total[3] = {0, 0, 0};
 		long t_count[3] = {0, 0, 0};
+		// one event pair per rownorm_kernel launch of the current predict call (GPLE_TIMER_PREDICT_KERNEL)
+		std::vector<hipEvent_t> chunk_ev;
+		int chunk_ev_used = 0;
 	};
+	void chunk_timer_start(Ctx* c);
+	void chunk_timer_stop(Ctx* c);
 	// record the start / stop event of timer `which` (no-ops unless timing is on); collect after a stream sync
 	void timer_start(Ctx* c, int which);
 	void timer_stop(Ctx* c, int which);

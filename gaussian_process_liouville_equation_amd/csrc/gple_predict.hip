@@ -1,21 +1,27 @@
-// gple_predict.hip — fused GP prediction kernel for gfx950 (the dominant kernel of the fit+predict step).
+// gple_predict.hip — GP prediction kernels for gfx950 (the dominant part of the fit+predict step).
 //
 // Reference hot loop 4 (kernel.cpp:495-518, complex_kernel.cpp:608-642):
-//     mu_i  = K*_i v                      (M x N Gram row times weights)
+//     mu_i  = K*_i v                        (M x N Gram row times weights)
 //     var_i = k(x*,x*) - K*_i K^-1 K*_i^T   (one N x N GEMV + dot per test point, 2 M N^2 flops)
-// The reference materialises the M x N matrix K* and the explicit inverse.  Here
+// The reference materialises the whole M x N matrix K* and the explicit inverse.  Here
 //   * K^-1 = T^T T with T = chol(K)^-1 lower triangular, so  K*_i K^-1 K*_i^T = || T K*_i^T ||^2  — a triangular
 //     contraction (M N^2 flops) whose result is a sum of squares (no cancellation inside the quadratic form);
-//   * K* is never written to HBM: every 128 x 16 slab of it is generated straight into LDS (exp on the VALU) and
-//     consumed as the MFMA operand; the only HBM/L2 stream is T (read once per 128-row tile of test points);
-//   * the row norms are accumulated in registers across all N-tiles, the mean is accumulated while the slab for the
-//     last N-tile (which spans every k) is generated.
-// One workgroup = 8 waves owns 128 test rows and loops over 256-wide N-tiles; K advances 16 per step through a
-// double-buffered LDS stage (A: generated 16 x 128, B: 16 x 256 of T).  Each wave owns 16 rows x all 256 columns
-// (16 accumulator tiles): every wave then sees the same triangular structure, so the all-zero 16 x 16 blocks of T
-// (k > n) are skipped by all waves alike and nobody idles behind the per-step barrier (a 2 x 4 wave grid left whole
-// SIMDs idle in the diagonal region: measured 51 % -> see profiles/).  v_mfma_f64_16x16x4_f64 with the result rows
-// on n and the result columns (lane & 15) on the test row m, so that the squared row sums stay lane-local.
+//   * kstar_gen_kernel writes one bounded chunk of K* (<= PREDICT_SCRATCH_BYTES, column-major chunk_rows x n) to a
+//     rolling HBM scratch and reduces the mean on the way (pure VALU: one exp per element, once);
+//   * rownorm_kernel streams that chunk and T through LDS into v_mfma_f64_16x16x4_f64 and keeps only the squared
+//     row norms.
+// Why two kernels (measured on MI355X, see profiles/ and probes/): fp64 MFMA and fp64 VALU share one pipe, every
+// VALU instruction of a co-resident wave adds ~4.4 cycles to the MFMA stream, and a fused kernel has to re-generate
+// each K* element once per 256-column tile of T it meets (N/512 times on average, 32 fp64 instructions each).
+// Fused variants (lock-step, interleaved, wave-specialised ping-pong) all stalled at 52 TFLOP/s at N=4096; the plain
+// lock-step MFMA loop with LDS operand reads sustains 72.6 TFLOP/s on its own.
+//
+// rownorm_kernel: one workgroup = 8 waves owns 128 test rows and loops over 256-wide N-tiles of T; K advances 16 per
+// step through a double-buffered LDS stage (global -> registers -> LDS, loads issued before the MFMAs of the current
+// step).  Every wave owns 16 rows x all 256 columns (16 accumulator tiles), so the all-zero blocks of T (k > n) are
+// skipped by all waves alike; the skipping is expressed as consecutive loops with a compile-time block range because
+// any branch that merges around the accumulators makes hipcc spill hundreds of VGPRs.  The result rows sit on n and
+// the result columns (lane & 15) on the test row m, so the squared row sums stay lane-local.
 //
 // "Typed" rows/columns implement the complex GP as a real GP on [Re; Im] (see gple_kernels.h, SEParamSet).
 #include <type_traits>
@@ -30,100 +36,149 @@ namespace gple
 	namespace
 	{
 		constexpr int BM = 128, BN = 256, BK = 16;
-		constexpr int AS = BM + 16, BS = BN + 16;
+		constexpr int AS = BM + 16; // LDS row stride of the K* slab [k][m]
+		constexpr int BS = BN + 16; // LDS row stride of the T tile [k][n]
+		constexpr int A_SLAB = BK * AS, B_SLAB = BK * BS;
 		constexpr int NTHREADS = 512;
+		constexpr int GEN_KSPLIT = 8; // k-ranges per row in the generation kernel (partial means)
 
-		__global__ void __launch_bounds__(NTHREADS) predict_q_kernel(const PredictArgs a)
+		// exp(x) for finite x <= 0 (the argument of a squared-exponential kernel), fp64, < 1 ulp:
+		// x = k ln2 + r (Cody-Waite with an FMA), |r| <= ln2/2, degree-12 Taylor/Horner, scaling by v_ldexp_f64 (which
+		// handles the gradual underflow for x < -708).  No special-case branches.
+		__device__ __forceinline__ double exp_nonpos(double x)
 		{
-			__shared__ __attribute__((aligned(16))) double lds[2 * BK * AS + 2 * BK * BS];
-			double* const As = lds;
-			double* const Bs = lds + 2 * BK * AS;
+			x = fmax(x, -1100.0); // below that the result is 0 anyway; keeps the int conversion in range
+			const double kd = rint(x * 1.4426950408889634074);
+			double r = fma(kd, -6.93147180369123816490e-01, x);
+			r = fma(kd, -1.90821492927058770002e-10, r);
+			double p = 2.08767569878680989792e-09; // 1/12!
+			p = fma(p, r, 2.50521083854417187751e-08);
+			p = fma(p, r, 2.75573192239858906526e-07);
+			p = fma(p, r, 2.75573192239858906526e-06);
+			p = fma(p, r, 2.48015873015873015873e-05);
+			p = fma(p, r, 1.98412698412698412698e-04);
+			p = fma(p, r, 1.38888888888888888889e-03);
+			p = fma(p, r, 8.33333333333333333333e-03);
+			p = fma(p, r, 4.16666666666666666667e-02);
+			p = fma(p, r, 1.66666666666666666667e-01);
+			p = fma(p, r, 0.5);
+			p = fma(p, r, 1.0);
+			p = fma(p, r, 1.0);
+			return ldexp(p, static_cast<int>(kd));
+		}
 
+		// K*(row, k) = amp (exp(-((dx rl0)^2 + (dp rl1)^2)/2) + n2 [x* == x_k])  for the rows [row0, row0 + rows) of the
+		// typed test set -> Ks (column-major, ld = rows); partial means mu_part[ky][row] = sum_{k in range ky} K* v[k].
+		// One thread per row, blockIdx.y selects the k-range; the training point of each k is a scalar load.
+		__global__ void __launch_bounds__(128) kstar_gen_kernel(const PredictArgs a, int row0, int rows, double* __restrict__ Ks,
+			double* __restrict__ mu_part)
+		{
+			const int r = blockIdx.x * 128 + threadIdx.x; // row inside the chunk
+			const int gm = row0 + r;                       // row of the typed test set
+			const int type_m = (row0 + blockIdx.x * 128) >= a.m_split; // uniform per block (m_split multiple of 128)
+			int pidx = type_m ? gm - a.m_split : gm;
+			pidx = pidx < a.M ? pidx : a.M - 1; // rows beyond M are clamped (their results are never read)
+			const double xm = a.Xs[2 * pidx], pm = a.Xs[2 * pidx + 1];
+			const int kper = a.n_total / GEN_KSPLIT; // multiple of 32 (n_total is a multiple of 256)
+			const int kbeg = blockIdx.y * kper;
+			double mu = 0.0;
+			double* __restrict__ out = Ks + r + static_cast<long>(kbeg) * rows;
+			for (int k0 = kbeg; k0 < kbeg + kper; k0 += 4)
+			{
+				const int type_k = k0 >= a.n_split;
+				const SEParam& p = a.ps.p[type_m + type_k];
+				const double n2 = (type_m == type_k) ? p.n2 : 0.0;
+				const double amp = p.amp, rl0 = p.rl0, rl1 = p.rl1;
+#pragma unroll
+				for (int e = 0; e < 4; ++e)
+				{
+					const int k = k0 + e;
+					const int pk = type_k ? k - a.n_split : k;
+					const bool valid = pk < a.N;
+					const int pc = valid ? pk : 0;
+					const double xk = a.Xt[2 * pc], pkv = a.Xt[2 * pc + 1];
+					const double d0 = (xm - xk) * rl0, d1 = (pm - pkv) * rl1;
+					const double g = exp_nonpos(-0.5 * (d0 * d0 + d1 * d1));
+					const double delta = (xm == xk && pm == pkv) ? n2 : 0.0; // delta_kernel: exact equality, kernel.cpp:26
+					const double val = valid ? amp * (g + delta) : 0.0;
+					mu = fma(val, a.v[k], mu);
+					out[static_cast<long>(e) * rows] = val;
+				}
+				out += 4L * rows;
+			}
+			mu_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = mu;
+		}
+
+		// q[row] = sum_n ( sum_{k <= n} K*(row, k) T(n, k) )^2 for one chunk of rows
+		__global__ void __launch_bounds__(NTHREADS) rownorm_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T,
+			long ldt, int n_total, double* __restrict__ q)
+		{
+			__shared__ __attribute__((aligned(16))) double lds[2 * A_SLAB + 2 * B_SLAB];
+			double* const As = lds;
+			double* const Bs = lds + 2 * A_SLAB;
 			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
 			const int fk = lane >> 4, fr = lane & 15;
 			const int m0 = blockIdx.x * BM;
-			// this thread's test point (fixed for the whole kernel); rows beyond M are clamped and never stored
-			// kq is the same for all lanes of a wave; readfirstlane tells the compiler, so the training point and weight
-			// loads of gen_a become scalar (SMEM) loads
-			const int ml = t & 127, kq = __builtin_amdgcn_readfirstlane(t >> 7);
-			const int gm = m0 + ml;
-			const int type_m = m0 >= a.m_split; // uniform per workgroup (m_split is a multiple of BM)
-			int pidx = type_m ? gm - a.m_split : gm;
-			pidx = pidx < a.M ? pidx : a.M - 1;
-			const double xm = a.Xs[2 * pidx], pm = a.Xs[2 * pidx + 1];
-
+			const int ntiles = n_total / BN;
 			double rsq = 0.0;
-			double mu_acc = 0.0;
-			const int ntiles = a.n_total / BN;
 
-			// generate the A slab for k-tile k0 into buffer S; accumulate the mean when asked
-			auto gen_a = [&](double* __restrict__ S, int k0, bool with_mean) {
-				const int type_k = k0 >= a.n_split; // uniform per k-tile (n_split is a multiple of BK)
-				const SEParam& p = a.ps.p[type_m + type_k];
-				const double amp = p.amp, n2 = (type_m == type_k) ? p.n2 : 0.0, rl0 = p.rl0, rl1 = p.rl1;
-				const int kbase = k0 + kq * 4;
-#pragma unroll 2
-				for (int e = 0; e < 4; ++e)
+			d2 areg[2], breg[4];
+			auto load_ab = [&](int n0, int k0) {
+				const double* __restrict__ abase = Ks + m0 + static_cast<long>(k0) * rows;
+#pragma unroll
+				for (int qq = 0; qq < 2; ++qq)
 				{
-					const int k = kbase + e;
-					const int pk = type_k ? k - a.n_split : k;
-					double val = 0.0;
-					if (pk < a.N)
-					{
-						const double xk = a.Xt[2 * pk], pkv = a.Xt[2 * pk + 1];
-						const double d0 = (xm - xk) * rl0, d1 = (pm - pkv) * rl1;
-						const double g = exp(-0.5 * (d0 * d0 + d1 * d1));
-						const double delta = (xm == xk && pm == pkv) ? n2 : 0.0; // delta_kernel: exact equality, kernel.cpp:26
-						val = amp * (g + delta);
-						if (with_mean) mu_acc = fma(val, a.v[k], mu_acc);
-					}
-					S[(kq * 4 + e) * AS + ml] = val;
+					const int i = t + NTHREADS * qq;
+					const int r2 = (i & 63) * 2, k = i >> 6;
+					areg[qq] = *reinterpret_cast<const d2*>(abase + r2 + static_cast<long>(k) * rows);
+				}
+				const double* __restrict__ bbase = T + n0 + static_cast<long>(k0) * ldt;
+#pragma unroll
+				for (int qq = 0; qq < 4; ++qq)
+				{
+					const int i = t + NTHREADS * qq;
+					const int r2 = (i & 127) * 2, k = i >> 7;
+					breg[qq] = *reinterpret_cast<const d2*>(bbase + r2 + static_cast<long>(k) * ldt);
 				}
 			};
-			d2 breg[4];
-			auto load_b = [&](int n0, int k0) {
-				const double* __restrict__ base = a.T + n0 + static_cast<long>(k0) * a.ldt;
+			auto store_ab = [&](int buf) {
+				double* __restrict__ sa = As + buf * A_SLAB;
 #pragma unroll
-				for (int q = 0; q < 4; ++q)
+				for (int qq = 0; qq < 2; ++qq)
 				{
-					const int i = t + NTHREADS * q;
-					const int r2 = (i & 127) * 2, k = i >> 7;
-					breg[q] = *reinterpret_cast<const d2*>(base + r2 + static_cast<long>(k) * a.ldt);
+					const int i = t + NTHREADS * qq;
+					const int r2 = (i & 63) * 2, k = i >> 6;
+					*reinterpret_cast<d2*>(sa + k * AS + r2) = areg[qq];
 				}
-			};
-			auto store_b = [&](double* __restrict__ S) {
+				double* __restrict__ sb = Bs + buf * B_SLAB;
 #pragma unroll
-				for (int q = 0; q < 4; ++q)
+				for (int qq = 0; qq < 4; ++qq)
 				{
-					const int i = t + NTHREADS * q;
+					const int i = t + NTHREADS * qq;
 					const int r2 = (i & 127) * 2, k = i >> 7;
-					*reinterpret_cast<d2*>(S + k * BS + r2) = breg[q];
+					*reinterpret_cast<d2*>(sb + k * BS + r2) = breg[qq];
 				}
 			};
 
 			for (int jt = 0; jt < ntiles; ++jt)
 			{
 				const int n0 = jt * BN;
-				const int nk = (n0 + BN) / BK; // T(n,k) = 0 for k > n: k-tiles beyond the N-tile's last column are skipped
-				const bool with_mean = jt == ntiles - 1;
+				const int nk = (n0 + BN) / BK; // T(n,k) = 0 for k > n: k-slabs beyond the N-tile's last column are skipped
 				d4 acc[16];
 #pragma unroll
 				for (int j = 0; j < 16; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-				__syncthreads(); // the previous tile's last compute is done before the stage is refilled
-				gen_a(As, 0, with_mean);
-				load_b(n0, 0);
-				store_b(Bs);
+				__syncthreads(); // the previous tile's last MFMAs have finished reading the stage
+				load_ab(n0, 0);
+				store_ab(0);
 				__syncthreads();
-				// One k-step: MFMAs of slab `it` against the column blocks j >= JMIN, then stage slab it + 1.
-				// JMIN is a compile-time constant per loop: any branch that merges around the accumulators makes hipcc spill
-				// hundreds of VGPRs, so the triangular skipping is expressed as four consecutive loops instead.
-				auto kstep = [&](auto jmin_tag, int it) {
+
+				// one k-step: prefetch slab s + 1, MFMAs of slab s against the column blocks j >= JMIN, commit the prefetch
+				auto kstep = [&](auto jmin_tag, int s) {
 					constexpr int JMIN = decltype(jmin_tag)::value;
-					const int cur = it & 1, k0 = it * BK;
-					if (it + 1 < nk) load_b(n0, k0 + BK);
-					const double* __restrict__ pa = As + cur * BK * AS + w * 16 + fr;
-					const double* __restrict__ pb = Bs + cur * BK * BS + fr;
+					if (s + 1 < nk) load_ab(n0, (s + 1) * BK);
+					const double* __restrict__ pa = As + (s & 1) * A_SLAB + w * 16 + fr;
+					const double* __restrict__ pb = Bs + (s & 1) * B_SLAB + fr;
 #pragma unroll
 					for (int kk = 0; kk < BK; kk += 4)
 					{
@@ -138,55 +193,67 @@ namespace gple
 							for (int j = 0; j < 4; ++j) acc[h + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af, acc[h + j], 0, 0, 0);
 						}
 					}
-					if (it + 1 < nk)
-					{
-						gen_a(As + (cur ^ 1) * BK * AS, k0 + BK, with_mean);
-						store_b(Bs + (cur ^ 1) * BK * BS);
-					}
+					if (s + 1 < nk) store_ab((s + 1) & 1);
 					__syncthreads();
 				};
-				// k-steps below the diagonal N-tile and its first 64 columns see every column block; afterwards the column
+				// k-slabs below the diagonal N-tile and its first 64 columns see every column block; afterwards the column
 				// blocks left of the current k (T(n,k) = 0 for k > n) drop out, 64 columns at a time
 				const int nd = n0 / BK;
-				int it = 0;
-				for (; it < nd + 4; ++it) kstep(std::integral_constant<int, 0>{}, it);
-				for (; it < nd + 8; ++it) kstep(std::integral_constant<int, 4>{}, it);
-				for (; it < nd + 12; ++it) kstep(std::integral_constant<int, 8>{}, it);
-				for (; it < nd + 16; ++it) kstep(std::integral_constant<int, 12>{}, it);
+				int s = 0;
+				for (; s < nd + 4; ++s) kstep(std::integral_constant<int, 0>{}, s);
+				for (; s < nd + 8; ++s) kstep(std::integral_constant<int, 4>{}, s);
+				for (; s < nd + 12; ++s) kstep(std::integral_constant<int, 8>{}, s);
+				for (; s < nd + 16; ++s) kstep(std::integral_constant<int, 12>{}, s);
+
 				// result element [n = 16 j + fk + 4 r][m = 16 w + fr]: the row index m is lane-local
 #pragma unroll
 				for (int j = 0; j < 16; ++j)
 #pragma unroll
 					for (int r = 0; r < 4; ++r) rsq = fma(acc[j][r], acc[j][r], rsq);
 			}
-
-			// reduce over the four lane groups (same fr); the four k-quarters of the mean go through LDS
 			rsq += __shfl_xor(rsq, 16);
 			rsq += __shfl_xor(rsq, 32);
-			__syncthreads();
-			double* const red_q = lds;        // [128]
-			double* const red_mu = lds + 128; // [4 (kq)][128]
-			if (lane < 16) red_q[w * 16 + lane] = rsq;
-			red_mu[kq * 128 + ml] = mu_acc;
-			__syncthreads();
-			if (t < 128)
-			{
-				const int row = m0 + t;
-				const int prow = type_m ? row - a.m_split : row;
-				if (prow < a.M)
-				{
-					a.q[row] = red_q[t];
-					a.mu[row] = (red_mu[t] + red_mu[128 + t]) + (red_mu[256 + t] + red_mu[384 + t]);
-				}
-			}
+			if (lane < 16) q[m0 + w * 16 + lane] = rsq;
+		}
+
+		__global__ void __launch_bounds__(256) sum_mu_kernel(const double* __restrict__ mu_part, int m_rows, double* __restrict__ mu)
+		{
+			const int i = blockIdx.x * 256 + threadIdx.x;
+			if (i >= m_rows) return;
+			double s = 0.0;
+#pragma unroll
+			for (int ky = 0; ky < GEN_KSPLIT; ++ky) s += mu_part[static_cast<long>(ky) * m_rows + i];
+			mu[i] = s;
 		}
 	} // namespace
 
-	hipError_t launch_predict_q(hipStream_t s, const PredictArgs& a)
+	size_t predict_scratch_doubles(const PredictArgs& a, int* chunk_rows)
+	{
+		// rolling K* chunk: as many 128-row tiles as fit PREDICT_SCRATCH_BYTES (at least one), never more than needed
+		const size_t per_row = static_cast<size_t>(a.n_total) * sizeof(double);
+		size_t rows = PREDICT_SCRATCH_BYTES / per_row / BM * BM;
+		if (rows < static_cast<size_t>(BM)) rows = BM;
+		if (rows > static_cast<size_t>(a.m_rows)) rows = a.m_rows;
+		*chunk_rows = static_cast<int>(rows);
+		return rows * a.n_total + static_cast<size_t>(GEN_KSPLIT) * a.m_rows;
+	}
+
+	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows)
 	{
 		if (a.M <= 0) return hipSuccess;
-		if (a.m_rows % BM || a.n_total % BN || a.m_split % BM || a.n_split % BN) return hipErrorInvalidValue;
-		hipLaunchKernelGGL(predict_q_kernel, dim3(a.m_rows / BM), dim3(NTHREADS), 0, s, a);
+		if (a.m_rows % BM || a.n_total % BN || a.m_split % BM || a.n_split % BN || chunk_rows % BM || chunk_rows <= 0)
+			return hipErrorInvalidValue;
+		double* Ks = scratch;
+		double* mu_part = scratch + static_cast<size_t>(chunk_rows) * a.n_total;
+		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
+		{
+			const int rows = a.m_rows - row0 < chunk_rows ? a.m_rows - row0 : chunk_rows;
+			hipLaunchKernelGGL(kstar_gen_kernel, dim3(rows / 128, GEN_KSPLIT), dim3(128), 0, s, a, row0, rows, Ks, mu_part);
+			chunk_timer_start(ctx);
+			hipLaunchKernelGGL(rownorm_kernel, dim3(rows / BM), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
+			chunk_timer_stop(ctx);
+		}
+		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256), dim3(256), 0, s, mu_part, a.m_rows, a.mu);
 		return hipGetLastError();
 	}
 } // namespace gple

@@ -116,7 +116,7 @@ const char* gple_ctx_last_error(const gple_ctx* ctx);
 typedef enum gple_timer {
 	GPLE_TIMER_FIT = 0,            /* whole *_fit_create call (device side)                 */
 	GPLE_TIMER_PREDICT = 1,        /* whole *_predict call (device side)                    */
-	GPLE_TIMER_PREDICT_KERNEL = 2  /* the fused variance/mean kernel of *_predict alone     */
+	GPLE_TIMER_PREDICT_KERNEL = 2  /* the MFMA row-norm kernel of *_predict alone; count = its launches */
 } gple_timer;
 int gple_ctx_enable_timing(gple_ctx* ctx, int on);
 /* last: milliseconds of the most recent call; total / count: accumulated since enable (any may be NULL). */
