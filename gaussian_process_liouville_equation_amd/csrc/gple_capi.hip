@@ -189,6 +189,8 @@ struct FitCommon
 	double* w = nullptr;    // n_total (diag of K^-1)
 	double* wx = nullptr;   // Np (complex only)
 	double* W = nullptr;    // n_total^2, lazy
+	double* dv = nullptr;   // derivatives of v over the parameters, [nparam][n_total] (GPLE_CALC_DERIVATIVE fits only)
+	double sf = 1.0;        // real kernel: magnitude (needed unsquared by the derivative formulas)
 	double* sdev = nullptr; // [0] rescale factor, [1..] raw sums, [31] info (as int)
 	double s_host = 0.0;
 	SEParamSet ps{};
@@ -198,7 +200,7 @@ struct FitCommon
 	~FitCommon()
 	{
 		if (!ctx) return;
-		for (double* p : {Xt, ys, T, v, w, wx, W, sdev}) ctx->give_back(p);
+		for (double* p : {Xt, ys, T, v, w, wx, W, dv, sdev}) ctx->give_back(p);
 	}
 };
 struct gple_real_fit: FitCommon
@@ -283,6 +285,60 @@ namespace
 		GPLE_HIP(ctx, trtri_lower_from_diag(st, Lbuf.p, nt, f->T, nt, nt, work.p));
 		GPLE_HIP(ctx, launch_trmv_lower(st, f->T, nt, nt, f->ys, part.p, u.p));
 		GPLE_HIP(ctx, launch_colpass(st, f->T, nt, nt, u.p, f->v, f->w, Np, f->wx));
+		return GPLE_OK;
+	}
+
+	// TrainingKernel derivative members (kernel.cpp:337-477) for the real kernel; raw sums land in sdev[16..28]
+	int real_fit_derivatives(gple_ctx* ctx, FitCommon* f, double sf, double l0, double l1, double sn, unsigned flags)
+	{
+		hipStream_t st = ctx->stream;
+		const int nt = f->n_total;
+		const size_t n2 = static_cast<size_t>(nt) * nt;
+		GPLE_TRY(ensure_inverse(f));
+		hipError_t e;
+		f->dv = ctx->acquire(4 * static_cast<size_t>(nt) * 8, &e);
+		GPLE_HIP(ctx, e);
+		Scratch D(ctx), C(ctx), part(ctx), tvec(ctx), dwd(ctx), qpart(ctx);
+		GPLE_HIP(ctx, D.get(2 * n2));
+		GPLE_HIP(ctx, C.get(n2));
+		GPLE_HIP(ctx, part.get(static_cast<size_t>(nt / 256) * nt));
+		GPLE_HIP(ctx, tvec.get(nt));
+		GPLE_HIP(ctx, dwd.get(4 * static_cast<size_t>(nt)));
+		double* dv = f->dv;
+		GPLE_HIP(ctx, launch_deriv_gram(st, f->Xt, f->N, nt, f->ps.p[0], D.p, D.p + n2));
+		// magnitude: dW = -2 W / sf (:349)
+		GPLE_HIP(ctx, launch_scale(st, f->v, -2.0 / sf, nt, dv));
+		GPLE_HIP(ctx, launch_scale(st, f->w, -2.0 / sf, nt, dwd.p));
+		// lengths: dW = -W dK W (:354): (dW) y = -W (dK v), diag(dW)_i = -sum_j W(j,i) (dK W)(j,i)
+		for (int d = 0; d < 2; ++d)
+		{
+			const double* Dd = D.p + d * n2;
+			GPLE_HIP(ctx, launch_gemv(st, Dd, nt, nt, f->v, 1.0, part.p, tvec.p));
+			GPLE_HIP(ctx, launch_gemv(st, f->W, nt, nt, tvec.p, -1.0, part.p, dv + static_cast<size_t>(1 + d) * nt));
+			GemmDesc g{};
+			g.A = Dd, g.lda = nt, g.B = f->W, g.ldb = nt, g.C = C.p, g.ldc = nt;
+			g.M = nt, g.N = nt, g.K = nt, g.batch = 1, g.alpha = 1.0, g.beta = 0.0, g.krange = K_FULL, g.lower_only = 0;
+			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
+			GPLE_HIP(ctx, launch_gemm(st, g, (nt / 128) * (nt / 128) >= 256 ? 128 : 64));
+			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, C.p, nt, nt, 0, -1.0, dwd.p + static_cast<size_t>(1 + d) * nt));
+		}
+		// noise: dW = -2 sf^2 sn W W (:358)
+		const double cn = -2.0 * (sf * sf) * sn;
+		GPLE_HIP(ctx, launch_gemv(st, f->W, nt, nt, f->v, cn, part.p, dv + 3 * static_cast<size_t>(nt)));
+		GPLE_HIP(ctx, launch_coldot(st, f->W, nt, f->W, nt, nt, 0, cn, dwd.p + 3 * static_cast<size_t>(nt)));
+		GPLE_HIP(ctx, launch_real_deriv_sums(st, f->v, f->w, dv, dwd.p, f->N, nt, f->sdev + 16));
+		if (flags & GPLE_CALC_AVERAGE)
+		{
+			const size_t g = (static_cast<size_t>(f->N) + 63) / 64;
+			GPLE_HIP(ctx, qpart.get(g * g));
+			const SEParam k1 = purity_aux(sf, l0, l1);
+			for (int d = 0; d < 2; ++d) // v^T (dK1/dl'_d) v and dv_d^T K1 v
+			{
+				GPLE_HIP(ctx, launch_quadform(st, f->Xt, f->N, k1, f->v, f->v, d, qpart.p, f->sdev + 24 + d));
+				GPLE_HIP(ctx, launch_quadform(st, f->Xt, f->N, k1, dv + static_cast<size_t>(1 + d) * nt, f->v, -1, qpart.p, f->sdev + 26 + d));
+			}
+			GPLE_HIP(ctx, launch_quadform(st, f->Xt, f->N, k1, dv + 3 * static_cast<size_t>(nt), f->v, -1, qpart.p, f->sdev + 28));
+		}
 		return GPLE_OK;
 	}
 
@@ -524,7 +580,6 @@ extern "C"
 	{
 		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 20)) return GPLE_ERR_BAD_ARG;
 		*out = nullptr;
-		if (flags & GPLE_CALC_DERIVATIVE) return GPLE_ERR_STATE; // TODO(round 1): derivative path
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		gple_real_fit* f = new (std::nothrow) gple_real_fit;
@@ -533,6 +588,7 @@ extern "C"
 		const double sf = theta[0], l0 = theta[1], l1 = theta[2], sn = theta[3];
 		f->ps.p[0] = f->ps.p[1] = f->ps.p[2] = make_se(sf * sf, sn * sn, l0, l1);
 		f->self = (sf * sf) * (1.0 + (sn * sn) * 1.0); // KernelBase(params, col, col).get_kernel().value(), kernel.cpp:512
+		f->sf = sf;
 		hipStream_t st = ctx->stream;
 		int status = fit_common(ctx, f, X, y, y_is_complex ? 2 : 1, N, flags);
 		if (status == GPLE_OK)
@@ -543,13 +599,18 @@ extern "C"
 				Scratch part(ctx);
 				const size_t g = (N + 63) / 64;
 				e = part.get(g * g);
-				if (e == hipSuccess) e = launch_quadform(st, f->Xt, f->N, purity_aux(sf, l0, l1), f->v, f->v, part.p, f->sdev + 6);
+				if (e == hipSuccess) e = launch_quadform(st, f->Xt, f->N, purity_aux(sf, l0, l1), f->v, f->v, -1, part.p, f->sdev + 6);
+			}
+			if (e == hipSuccess && (flags & GPLE_CALC_DERIVATIVE))
+			{
+				status = real_fit_derivatives(ctx, f, sf, l0, l1, sn, flags);
+				if (status != GPLE_OK) e = hipErrorUnknown;
 			}
 			if (e == hipSuccess) e = hipMemcpyAsync(ctx->host_scalars, f->sdev, 32 * 8, hipMemcpyDeviceToHost, st);
 			timer_stop(ctx, GPLE_TIMER_FIT);
 			if (e == hipSuccess) e = hipStreamSynchronize(st);
 			timer_collect(ctx);
-			if (e != hipSuccess) status = record_hip_error(ctx, e, "real fit reductions", __LINE__);
+			if (e != hipSuccess && status == GPLE_OK) status = record_hip_error(ctx, e, "real fit reductions", __LINE__);
 		}
 		if (status != GPLE_OK)
 		{
@@ -580,6 +641,28 @@ extern "C"
 			sc.first_order_average[1] = GlobalFactor * (sf * sf) * lprod * h[4] / s;
 			const double PurityGlobal = (2.0 * M_PI) * M_PI; // PurityFactor * pi^Dim, :330
 			sc.purity = PurityGlobal * h[6] / (s * s);        // :331
+		}
+		if (flags & GPLE_CALC_DERIVATIVE)
+		{
+			if (flags & GPLE_CALC_ERROR)
+				for (int ip = 0; ip < 4; ++ip) sc.error_derivative[ip] = h[16 + ip]; // kernel.cpp:381-400
+			if (flags & GPLE_CALC_AVERAGE)
+			{
+				// kernel.cpp:401-435
+				const double ThisTimeFactor = (2.0 * M_PI) * (sf * sf) * (l0 * l1);
+				const double ls[2] = {l0, l1};
+				sc.population_derivative[0] = 0.0;
+				for (int d = 0; d < 2; ++d) sc.population_derivative[1 + d] = ThisTimeFactor * (h[2] / ls[d] + h[21 + d]);
+				sc.population_derivative[3] = ThisTimeFactor * h[23];
+				for (double& d : sc.population_derivative) d /= s;
+				// kernel.cpp:436-477
+				const double PurityGlobal = (2.0 * M_PI) * M_PI;
+				sc.purity_derivative[0] = 0.0;
+				for (int d = 0; d < 2; ++d)
+					sc.purity_derivative[1 + d] = ((h[6] / ls[d] + std::sqrt(2.0) * h[24 + d]) + 2.0 * h[26 + d]) * PurityGlobal;
+				sc.purity_derivative[3] = 2.0 * PurityGlobal * h[28];
+				for (double& d : sc.purity_derivative) d /= s * s;
+			}
 		}
 		if (scalars) *scalars = sc;
 		*out = f;
@@ -631,7 +714,10 @@ extern "C"
 		case GPLE_R_INVLBL: GPLE_HIP(ctx, hipMemcpyAsync(dst, f->v, N * 8, kind, st)); break;
 		case GPLE_R_LABEL: GPLE_HIP(ctx, hipMemcpyAsync(dst, f->ys, N * 8, kind, st)); break;
 		case GPLE_R_INVERSE_DIAG: GPLE_HIP(ctx, hipMemcpyAsync(dst, f->w, N * 8, kind, st)); break;
-		case GPLE_R_INVLBL_DERIV: return GPLE_ERR_STATE;
+		case GPLE_R_INVLBL_DERIV:
+			if (!f->dv) return GPLE_ERR_STATE;
+			GPLE_HIP(ctx, hipMemcpy2DAsync(dst, N * 8, f->dv, static_cast<size_t>(f->n_total) * 8, N * 8, 4, kind, st));
+			break;
 		default: return GPLE_ERR_BAD_ARG;
 		}
 		GPLE_HIP(ctx, hipStreamSynchronize(st));
@@ -648,7 +734,8 @@ extern "C"
 			for (double& d : scalars->error_derivative) d = nan_();
 		}
 		if (M == 0) return GPLE_OK;
-		if ((flags & GPLE_CALC_DERIVATIVE) && labels) return GPLE_ERR_STATE; // TODO(round 1): derivative path
+		const bool want_deriv = (flags & GPLE_CALC_DERIVATIVE) && labels;
+		if (want_deriv && (!f->dv || f->is_complex)) return GPLE_ERR_STATE; // needs a fit built with GPLE_CALC_DERIVATIVE
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
@@ -658,7 +745,7 @@ extern "C"
 		const int Mh = static_cast<int>(round_up(M, 128));
 		const int m_rows = cplx ? 2 * Mh : Mh;
 		const size_t ow = cplx ? 2 : 1; // doubles per prediction entry
-		Scratch xs(ctx), q(ctx), mu(ctx), lab(ctx), o_mean(ctx), o_var(ctx), o_cut(ctx), epart(ctx);
+		Scratch xs(ctx), q(ctx), mu(ctx), lab(ctx), o_mean(ctx), o_var(ctx), o_cut(ctx), epart(ctx), dacc(ctx), dpart(ctx);
 		timer_start(ctx, GPLE_TIMER_PREDICT);
 		const double* xs_dev = Xs;
 		if (!dev)
@@ -673,6 +760,11 @@ extern "C"
 		a.Xs = xs_dev, a.M = Mi, a.m_rows = m_rows, a.m_split = cplx ? Mh : m_rows;
 		a.Xt = f->Xt, a.N = f->N, a.n_total = f->n_total, a.n_split = cplx ? f->Np : f->n_total;
 		a.T = f->T, a.ldt = f->n_total, a.v = f->v, a.q = q.p, a.mu = mu.p, a.ps = f->ps;
+		if (want_deriv)
+		{
+			GPLE_HIP(ctx, dacc.get(7 * static_cast<size_t>(m_rows)));
+			a.dv = f->dv, a.dacc = dacc.p;
+		}
 		int chunk_rows = 0;
 		Scratch kstar(ctx);
 		GPLE_HIP(ctx, kstar.get(predict_scratch_doubles(a, &chunk_rows)));
@@ -719,6 +811,12 @@ extern "C"
 			GPLE_HIP(ctx, launch_sum(st, err_part, nblk, err_part + nblk));
 			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 32, err_part + nblk, 8, hipMemcpyDeviceToHost, st));
 		}
+		if (want_deriv)
+		{
+			GPLE_HIP(ctx, dpart.get(4 * static_cast<size_t>(nblk) + 4));
+			GPLE_HIP(ctx, launch_predict_deriv_finish_real(st, dacc.p, m_rows, q.p, Mi, f->self, f->sf, f->sdev, lab_dev, dpart.p, dpart.p + 4 * nblk));
+			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 40, dpart.p + 4 * nblk, 4 * 8, hipMemcpyDeviceToHost, st));
+		}
 		if (!dev)
 		{
 			GPLE_HIP(ctx, copy_out(st, prediction, d_mean, ow * M, false));
@@ -734,6 +832,8 @@ extern "C"
 			timer_collect(ctx);
 		}
 		if (labels && scalars) scalars->error = ctx->host_scalars[32];
+		if (want_deriv && scalars)
+			for (int ip = 0; ip < 4; ++ip) scalars->error_derivative[ip] = ctx->host_scalars[40 + ip];
 		return GPLE_OK;
 	}
 
@@ -794,7 +894,7 @@ extern "C"
 				const SEParam ks[6] = {aR, aI, aC, aC, aRC, aIC};
 				const double* as[6] = {wr, wi, wr, wi, wr, wr};
 				const double* bs[6] = {wr, wi, wr, wi, wi, wi};
-				for (int q = 0; q < 6 && e == hipSuccess; ++q) e = launch_quadform(st, f->Xt, f->N, ks[q], as[q], bs[q], part.p, f->sdev + 8 + q);
+				for (int q = 0; q < 6 && e == hipSuccess; ++q) e = launch_quadform(st, f->Xt, f->N, ks[q], as[q], bs[q], -1, part.p, f->sdev + 8 + q);
 			}
 			if (e == hipSuccess) e = hipMemcpyAsync(ctx->host_scalars, f->sdev, 32 * 8, hipMemcpyDeviceToHost, st);
 			timer_stop(ctx, GPLE_TIMER_FIT);
@@ -916,10 +1016,48 @@ extern "C"
 	}
 
 	// ---- not yet on the device (round 1 TODO): fail loudly, never fall back to the CPU ---------------------------
-	int gple_loose_function(gple_ctx*, const double*, size_t, const double*, const double*, size_t, const double*, const double*, size_t,
-		double*, double*)
+	// loose_function (opt.cpp:441-482)
+	int gple_loose_function(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N, const double* X_extra,
+		const double* y_extra, size_t M_extra, double* value, double* grad)
 	{
-		return GPLE_ERR_STATE;
+		if (!ctx || !x || !X || !y || !value || (n != 4 && n != 8) || (M_extra && (!X_extra || !y_extra))) return GPLE_ERR_BAD_ARG;
+		const unsigned flags = GPLE_CALC_ERROR | (grad ? GPLE_CALC_DERIVATIVE : 0u);
+		gple_predict_scalars ps;
+		double result = 0.0;
+		if (n == 4)
+		{
+			gple_real_fit_scalars sc;
+			gple_real_fit* fit = nullptr;
+			GPLE_TRY(gple_real_fit_create(ctx, x, X, y, 1, N, flags, &sc, &fit));
+			std::vector<double> lab(M_extra);
+			for (size_t i = 0; i < M_extra; ++i) lab[i] = y_extra[2 * i]; // ExtraTrainingLabel.real(), opt.cpp:451
+			const int st = gple_real_predict(ctx, fit, X_extra, M_extra, flags & GPLE_CALC_DERIVATIVE, lab.data(), nullptr, nullptr, nullptr, &ps);
+			gple_real_fit_release(fit);
+			GPLE_TRY(st);
+			result = sc.error + (M_extra ? ps.error : 0.0);
+			if (grad)
+				for (int i = 0; i < 4; ++i) grad[i] = sc.error_derivative[i] + (M_extra ? ps.error_derivative[i] : 0.0);
+		}
+		else
+		{
+			if (grad) return GPLE_ERR_STATE; // TODO(round 2): complex derivative path on the device
+			gple_complex_fit_scalars sc;
+			gple_complex_fit* fit = nullptr;
+			GPLE_TRY(gple_complex_fit_create(ctx, x, X, y, N, flags, &sc, &fit));
+			const int st = gple_complex_predict(ctx, fit, X_extra, M_extra, 0, y_extra, nullptr, nullptr, nullptr, &ps);
+			gple_complex_fit_release(fit);
+			GPLE_TRY(st);
+			result = sc.error + (M_extra ? ps.error : 0.0);
+		}
+		// make_normal, opt.cpp:420-431
+		auto make_normal = [](double& d) {
+			if (std::isnan(d) || std::isinf(d)) d = std::numeric_limits<double>::max();
+		};
+		make_normal(result);
+		if (grad)
+			for (size_t i = 0; i < n; ++i) make_normal(grad[i]);
+		*value = result;
+		return GPLE_OK;
 	}
 	int gple_nlml(gple_ctx*, const double[4], const double*, const double*, size_t, double*, double*) { return GPLE_ERR_STATE; }
 	int gple_nlml_predict(gple_ctx*, const double[4], const double*, const double*, size_t, const double*, size_t, unsigned, double*)

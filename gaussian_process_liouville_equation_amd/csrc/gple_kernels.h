@@ -38,8 +38,25 @@ namespace gple
 	hipError_t launch_real_fit_sums(hipStream_t s, const double* Xt, const double* ys, const double* v, const double* w, int N,
 		double* out);
 	// out[0] = sum_ij a_i k(x_i,x_j) b_j over i,j < N with the bit-faithful SE kernel p (amp folded in, no noise)
-	hipError_t launch_quadform(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, double* part,
+	// fdim >= 0 multiplies every entry by ((x_i,d - x_j,d)/l_d)^2 / l_d: the kernel's derivative over l_d (kernel.cpp:99-160)
+	hipError_t launch_quadform(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, int fdim, double* part,
 		double* out);
+
+	// ---- derivative path (gple_deriv.hip) ------------------------------------------------------------------------
+	// D0, D1 (n x n, ld = n, padded with zeros): dK/dl_d of the training Gram, zero diagonal (kernel.cpp:123-157, 190)
+	hipError_t launch_deriv_gram(hipStream_t s, const double* Xt, int N, int n, SEParam p, double* D0, double* D1);
+	// y = alpha * A x for a full column-major n x n matrix (n multiple of 256); part: (n/256) * n doubles
+	hipError_t launch_gemv(hipStream_t s, const double* A, long lda, int n, const double* x, double alpha, double* part, double* y);
+	// out[i] = alpha * sum_j A(j,i) B(j,i + shift)   (columns i with i + shift < n; shift = 0: plain column dots)
+	hipError_t launch_coldot(hipStream_t s, const double* A, long lda, const double* B, long ldb, int n, int shift, double alpha,
+		double* out);
+	hipError_t launch_scale(hipStream_t s, const double* x, double alpha, int n, double* y);
+	// raw sums of the real derivative path: out[ip] = error derivative (kernel.cpp:381-400), out[4 + ip] = sum_i dv[ip][i]
+	hipError_t launch_real_deriv_sums(hipStream_t s, const double* v, const double* w, const double* dv, const double* dwd, int N, int ld,
+		double* out);
+	// PredictiveKernel::ErrorDerivatives (kernel.cpp:524-542) from the per-row accumulators of the derivative generation pass
+	hipError_t launch_predict_deriv_finish_real(hipStream_t s, const double* acc, int m_rows, const double* q, int M, double self, double sf,
+		const double* s_dev, const double* labels, double* part, double* out4);
 
 	// ---- KernelBase / cutoff ----------------------------------------------------------------------------------
 	// p.amp = sf*sf, p.n2 = sn*sn; sf and sn are passed too because the derivative formulas use them unsquared.
@@ -62,6 +79,8 @@ namespace gple
 		const double* T;
 		long ldt;
 		const double* v; // n_total weights (K^-1 y in the typed basis)
+		const double* dv; // derivative pass (real GP): 4 x n_total derivatives of v, or nullptr
+		double* dacc;     // derivative pass: 7 x m_rows accumulators [K* v, K* dv_0..3, (dK*/dl_0) v, (dK*/dl_1) v]
 		double* q;       // m_rows: || T k*_m ||^2
 		double* mu;      // m_rows: k*_m . v
 		SEParamSet ps;

@@ -186,8 +186,9 @@ namespace gple
 			}
 		}
 
+		// fdim < 0: sum a_i k_ij b_j ; fdim = d: sum a_i (k_ij ((x_i,d - x_j,d)/l_d)^2 / l_d) b_j  (kernel.cpp:99-160)
 		__global__ void __launch_bounds__(256) quadform_kernel(const double* __restrict__ Xt, int N, SEParam p, const double* __restrict__ a,
-			const double* __restrict__ b, double* __restrict__ part)
+			const double* __restrict__ b, int fdim, double* __restrict__ part)
 		{
 			__shared__ double red[4];
 			__shared__ double xj[64 * 2], bj[64];
@@ -212,7 +213,14 @@ namespace gple
 					if (j0 + jl < N)
 					{
 						const double g = se_exact(x0, x1, xj[2 * jl], xj[2 * jl + 1], p.l0, p.l1);
-						acc += ai * (p.amp * g) * bj[jl];
+						double kij = p.amp * g;
+						if (fdim >= 0)
+						{
+							const double l = fdim == 0 ? p.l0 : p.l1;
+							const double d = ((fdim == 0 ? x0 : x1) - xj[2 * jl + fdim]) / l;
+							kij *= d * d / l;
+						}
+						acc += ai * kij * bj[jl];
 					}
 				}
 			}
@@ -370,10 +378,11 @@ namespace gple
 		hipLaunchKernelGGL(real_fit_sums_kernel, dim3(1), dim3(1024), 0, s, Xt, ys, v, w, N, out);
 		return hipGetLastError();
 	}
-	hipError_t launch_quadform(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, double* part, double* out)
+	hipError_t launch_quadform(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, int fdim, double* part,
+		double* out)
 	{
 		const int g = (N + 63) / 64;
-		hipLaunchKernelGGL(quadform_kernel, dim3(g, g), dim3(256), 0, s, Xt, N, p, a, b, part);
+		hipLaunchKernelGGL(quadform_kernel, dim3(g, g), dim3(256), 0, s, Xt, N, p, a, b, fdim, part);
 		hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, part, g * g, out);
 		return hipGetLastError();
 	}

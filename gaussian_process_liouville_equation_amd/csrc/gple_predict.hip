@@ -70,6 +70,9 @@ namespace gple
 		// K*(row, k) = amp (exp(-((dx rl0)^2 + (dp rl1)^2)/2) + n2 [x* == x_k])  for the rows [row0, row0 + rows) of the
 		// typed test set -> Ks (column-major, ld = rows); partial means mu_part[ky][row] = sum_{k in range ky} K* v[k].
 		// One thread per row, blockIdx.y selects the k-range; the training point of each k is a scalar load.
+		// DERIV (real GP only): also accumulates K* dv_ip (ip = 0..3) and (dK*/dl_d) v (d = 0, 1) per row for
+		// PredictiveKernel::ErrorDerivatives (kernel.cpp:524-542); mu_part then holds 7 planes of GEN_KSPLIT x m_rows.
+		template <bool DERIV>
 		__global__ void __launch_bounds__(128) kstar_gen_kernel(const PredictArgs a, int row0, int rows, double* __restrict__ Ks,
 			double* __restrict__ mu_part)
 		{
@@ -82,6 +85,7 @@ namespace gple
 			const int kper = a.n_total / GEN_KSPLIT; // multiple of 32 (n_total is a multiple of 256)
 			const int kbeg = blockIdx.y * kper;
 			double mu = 0.0;
+			double dacc[6] = {0, 0, 0, 0, 0, 0};
 			double* __restrict__ out = Ks + r + static_cast<long>(kbeg) * rows;
 			for (int k0 = kbeg; k0 < kbeg + kper; k0 += 4)
 			{
@@ -102,11 +106,23 @@ namespace gple
 					const double delta = (xm == xk && pm == pkv) ? n2 : 0.0; // delta_kernel: exact equality, kernel.cpp:26
 					const double val = valid ? amp * (g + delta) : 0.0;
 					mu = fma(val, a.v[k], mu);
+					if constexpr (DERIV)
+					{
+#pragma unroll
+						for (int ip = 0; ip < 4; ++ip) dacc[ip] = fma(val, a.dv[static_cast<long>(ip) * a.n_total + k], dacc[ip]);
+						// dK*/dl_d = K* ((x*_d - x_d)/l_d)^2 / l_d  (test-set branch: K* with its noise delta, kernel.cpp:196)
+						const double vk = val * a.v[k];
+						dacc[4] = fma(vk, d0 * d0 * rl0, dacc[4]);
+						dacc[5] = fma(vk, d1 * d1 * rl1, dacc[5]);
+					}
 					out[static_cast<long>(e) * rows] = val;
 				}
 				out += 4L * rows;
 			}
 			mu_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = mu;
+			if constexpr (DERIV)
+#pragma unroll
+				for (int ip = 0; ip < 6; ++ip) mu_part[(static_cast<long>(ip + 1) * GEN_KSPLIT + blockIdx.y) * a.m_rows + gm] = dacc[ip];
 		}
 
 		// q[row] = sum_n ( sum_{k <= n} K*(row, k) T(n, k) )^2 for one chunk of rows
@@ -216,14 +232,16 @@ namespace gple
 			if (lane < 16) q[m0 + w * 16 + lane] = rsq;
 		}
 
-		__global__ void __launch_bounds__(256) sum_mu_kernel(const double* __restrict__ mu_part, int m_rows, double* __restrict__ mu)
+		// plane blockIdx.y of the partial sums -> out[plane][row]
+		__global__ void __launch_bounds__(256) sum_mu_kernel(const double* __restrict__ mu_part, int m_rows, double* __restrict__ out)
 		{
 			const int i = blockIdx.x * 256 + threadIdx.x;
 			if (i >= m_rows) return;
+			const double* __restrict__ p = mu_part + static_cast<long>(blockIdx.y) * GEN_KSPLIT * m_rows;
 			double s = 0.0;
 #pragma unroll
-			for (int ky = 0; ky < GEN_KSPLIT; ++ky) s += mu_part[static_cast<long>(ky) * m_rows + i];
-			mu[i] = s;
+			for (int ky = 0; ky < GEN_KSPLIT; ++ky) s += p[static_cast<long>(ky) * m_rows + i];
+			out[static_cast<long>(blockIdx.y) * m_rows + i] = s;
 		}
 	} // namespace
 
@@ -235,7 +253,7 @@ namespace gple
 		if (rows < static_cast<size_t>(BM)) rows = BM;
 		if (rows > static_cast<size_t>(a.m_rows)) rows = a.m_rows;
 		*chunk_rows = static_cast<int>(rows);
-		return rows * a.n_total + static_cast<size_t>(GEN_KSPLIT) * a.m_rows;
+		return rows * a.n_total + static_cast<size_t>(GEN_KSPLIT) * a.m_rows * (a.dv ? 7 : 1);
 	}
 
 	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows)
@@ -248,12 +266,15 @@ namespace gple
 		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
 		{
 			const int rows = a.m_rows - row0 < chunk_rows ? a.m_rows - row0 : chunk_rows;
-			hipLaunchKernelGGL(kstar_gen_kernel, dim3(rows / 128, GEN_KSPLIT), dim3(128), 0, s, a, row0, rows, Ks, mu_part);
+			if (a.dv) hipLaunchKernelGGL(kstar_gen_kernel<true>, dim3(rows / 128, GEN_KSPLIT), dim3(128), 0, s, a, row0, rows, Ks, mu_part);
+			else hipLaunchKernelGGL(kstar_gen_kernel<false>, dim3(rows / 128, GEN_KSPLIT), dim3(128), 0, s, a, row0, rows, Ks, mu_part);
 			chunk_timer_start(ctx);
 			hipLaunchKernelGGL(rownorm_kernel, dim3(rows / BM), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
 			chunk_timer_stop(ctx);
 		}
-		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256), dim3(256), 0, s, mu_part, a.m_rows, a.mu);
+		// a.mu receives plane 0 (the mean); with derivatives a.dacc receives all 7 planes (plane 0 = the mean again)
+		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, a.mu);
+		if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 7), dim3(256), 0, s, mu_part, a.m_rows, a.dacc);
 		return hipGetLastError();
 	}
 } // namespace gple

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("name", parity.REAL_FIXTURES)
 def test_real_fixture(gpu, name):
-    parity.check_real_case(gpu, load_golden(name), deriv=False)
+    parity.check_real_case(gpu, load_golden(name), deriv=True)
 
 
 @pytest.mark.parametrize("name,tol", parity.COMPLEX_FIXTURES)
@@ -159,3 +159,32 @@ def test_device_pointer_io_matches_host_io(gpu):
     gpu.synchronize()
     o = out.cpu().numpy()
     assert np.array_equal(o[0], ph["prediction"]) and np.array_equal(o[1], ph["variance"]) and np.array_equal(o[2], ph["cutoff"])
+
+
+def test_loose_function_real_matches_fixture_and_oracle(gpu, oracle):
+    """opt.cpp:441-482: objective = LOOCV error + validation error, gradient = sum of both derivative sets."""
+    g = load_golden("real_a")
+    val, grad = gpu.loose_function(g["theta"], g["X"], g["y"].astype(complex), g["Xv"], g["tv"].astype(complex))
+    tol = parity.cond_tol(g)
+    assert abs(val - (g["error"] + g["v_error"])) <= tol * abs(val)
+    ref = g["error_derivative"] + g["v_error_derivative"]
+    assert np.abs(grad - ref).max() <= 10 * tol * np.abs(ref).max()
+    # a larger, worse conditioned case against the oracle (reference's initial parameters, 5 N validation points)
+    X, y, _ = parity.synthetic_real(200, 1, 41)
+    rng = np.random.default_rng(42)
+    Xe = X[rng.integers(0, len(X), 5 * len(X))] + rng.normal(0, [0.7, 0.7], size=(5 * len(X), 2))
+    ye = np.exp(-0.5 * (((Xe[:, 0] + 10.0) / 0.7086) ** 2 + ((Xe[:, 1] - 14.112) / 0.7056) ** 2)) / (2 * np.pi * 0.7086 * 0.7056)
+    theta = [1.0, 0.7086, 0.7056, 1e-2]
+    vg, gg = gpu.loose_function(theta, X, y.astype(complex), Xe, ye.astype(complex))
+    vo, go = oracle.loose_function(theta, X, y.astype(complex), Xe, ye.astype(complex))
+    assert abs(vg - vo) <= 1e-6 * abs(vo)
+    assert np.abs(gg - go).max() <= 1e-5 * np.abs(go).max()
+    # value-only call (grad == NULL) takes the no-derivative path
+    v0, _ = gpu.loose_function(theta, X, y.astype(complex), Xe, ye.astype(complex), want_grad=False)
+    assert abs(v0 - vg) <= 1e-12 * abs(vg)
+
+
+def test_loose_function_complex_value(gpu, oracle):
+    g = load_golden("complex_a")
+    val, _ = gpu.loose_function(g["theta"], g["X"], g["y"], g["Xv"], g["tv"], want_grad=False)
+    assert abs(val - (g["error"] + g["v_error"])) <= 1e-9 * abs(val)
