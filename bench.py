@@ -80,7 +80,7 @@ def main():
     dy = torch.from_numpy(y).cuda()
     dgrid = torch.from_numpy(grid[lo:hi].copy()).cuda()
     out_local = torch.zeros(3, per, dtype=torch.float64, device="cuda")
-    out_full = torch.zeros(world, 3, per, dtype=torch.float64, device="cuda") if world > 1 else None
+    out_full = torch.zeros(world * 3, per, dtype=torch.float64, device="cuda") if world > 1 else None
     dp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))
     th = np.ascontiguousarray(theta)
     sc, ps = c.RealFitScalars(), c.PredictScalars()
