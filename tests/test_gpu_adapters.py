@@ -23,9 +23,9 @@ def test_cpp_adapters_match_python_path(gpu, tmp_path):
     with open(path, "w") as f:
         f.write(f"{len(X)} {len(Xs)}\n")
         for (a, b), z in zip(X, y):
-            f.write(f"{a!r} {b!r} {z.real!r} {z.imag!r}\n")
+            f.write("%.17g %.17g %.17g %.17g\n" % (a, b, z.real, z.imag))
         for a, b in Xs:
-            f.write(f"{a!r} {b!r}\n")
+            f.write("%.17g %.17g\n" % (a, b))
     out = subprocess.run([exe, str(path)], check=True, capture_output=True, text=True, timeout=120).stdout
     got = {l.split()[0]: np.array(list(map(float, l.split()[1:]))) for l in out.strip().splitlines()}
     theta = [1.0, 0.7086, 0.7056, 1e-2]
