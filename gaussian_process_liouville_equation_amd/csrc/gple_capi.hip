@@ -1015,7 +1015,6 @@ extern "C"
 		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
 	}
 
-	// ---- not yet on the device (round 1 TODO): fail loudly, never fall back to the CPU ---------------------------
 	// loose_function (opt.cpp:441-482)
 	int gple_loose_function(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N, const double* X_extra,
 		const double* y_extra, size_t M_extra, double* value, double* grad)
@@ -1059,9 +1058,91 @@ extern "C"
 		*value = result;
 		return GPLE_OK;
 	}
-	int gple_nlml(gple_ctx*, const double[4], const double*, const double*, size_t, double*, double*) { return GPLE_ERR_STATE; }
-	int gple_nlml_predict(gple_ctx*, const double[4], const double*, const double*, size_t, const double*, size_t, unsigned, double*)
+
+	// ---- negative_log_marginal_likelihood / predict_phase (test/gpr.cpp:499-532, 654-706) -------------------------------
+	// shared: Gram, Cholesky, inverse factor, b = K^-1 y (labels are NOT rescaled on this path)
+	static int nlml_solve(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, Scratch& Xt, Scratch& yd, Scratch& T,
+		Scratch& bvec, int* n_out)
 	{
-		return GPLE_ERR_STATE;
+		hipStream_t st = ctx->stream;
+		const int n = static_cast<int>(round_up(N, NPAD));
+		*n_out = n;
+		Scratch L(ctx), work(ctx), part(ctx), u(ctx), w(ctx), info(ctx);
+		GPLE_HIP(ctx, Xt.get(2 * static_cast<size_t>(n)));
+		GPLE_HIP(ctx, yd.get(n));
+		GPLE_HIP(ctx, T.get(static_cast<size_t>(n) * n));
+		GPLE_HIP(ctx, bvec.get(n));
+		GPLE_HIP(ctx, L.get(static_cast<size_t>(n) * n));
+		GPLE_HIP(ctx, work.get(static_cast<size_t>(n) * n / 4 + 64));
+		GPLE_HIP(ctx, part.get(static_cast<size_t>(n / 256) * n));
+		GPLE_HIP(ctx, u.get(n));
+		GPLE_HIP(ctx, w.get(n));
+		GPLE_HIP(ctx, info.get(1));
+		GPLE_HIP(ctx, hipMemsetAsync(Xt.p, 0, 2 * static_cast<size_t>(n) * 8, st));
+		GPLE_HIP(ctx, hipMemsetAsync(yd.p, 0, static_cast<size_t>(n) * 8, st));
+		GPLE_HIP(ctx, hipMemsetAsync(info.p, 0, 8, st));
+		GPLE_HIP(ctx, hipMemsetAsync(T.p, 0, static_cast<size_t>(n) * n * 8, st));
+		GPLE_HIP(ctx, copy_in(st, Xt.p, X, 2 * N, false));
+		GPLE_HIP(ctx, copy_in(st, yd.p, y, N, false));
+		GPLE_HIP(ctx, launch_nlml_gram(st, Xt.p, static_cast<int>(N), n, x, L.p));
+		GPLE_HIP(ctx, potrf_lower(st, L.p, n, n, T.p, n, reinterpret_cast<int*>(info.p)));
+		GPLE_HIP(ctx, trtri_lower_from_diag(st, L.p, n, T.p, n, n, work.p));
+		GPLE_HIP(ctx, launch_trmv_lower(st, T.p, n, n, yd.p, part.p, u.p));
+		GPLE_HIP(ctx, launch_colpass(st, T.p, n, n, u.p, bvec.p, w.p, 0, nullptr));
+		return GPLE_OK;
+	}
+
+	int gple_nlml(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, double* value, double* grad)
+	{
+		if (!ctx || !x || !X || !y || !value || N == 0) return GPLE_ERR_BAD_ARG;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		Scratch Xt(ctx), yd(ctx), T(ctx), b(ctx), out(ctx), W(ctx), part(ctx);
+		int n = 0;
+		GPLE_TRY(nlml_solve(ctx, x, X, y, N, Xt, yd, T, b, &n));
+		GPLE_HIP(ctx, out.get(8));
+		GPLE_HIP(ctx, launch_nlml_value(st, T.p, n, yd.p, b.p, static_cast<int>(N), out.p));
+		if (grad)
+		{
+			const size_t g = (N + 63) / 64;
+			GPLE_HIP(ctx, W.get(static_cast<size_t>(n) * n));
+			GPLE_HIP(ctx, part.get(4 * g * g));
+			GPLE_HIP(ctx, lauum_full(st, T.p, n, W.p, n, n));
+			GPLE_HIP(ctx, launch_nlml_grad(st, Xt.p, static_cast<int>(N), W.p, n, b.p, x, part.p, out.p + 1));
+		}
+		GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 48, out.p, 5 * 8, hipMemcpyDeviceToHost, st));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		*value = ctx->host_scalars[48];
+		if (grad)
+			for (int i = 0; i < 4; ++i) grad[i] = ctx->host_scalars[49 + i];
+		return GPLE_OK;
+	}
+
+	int gple_nlml_predict(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, const double* Xs, size_t M, unsigned flags,
+		double* mean)
+	{
+		if (!ctx || !x || !X || !y || N == 0 || (M && (!Xs || !mean))) return GPLE_ERR_BAD_ARG;
+		if (M == 0) return GPLE_OK;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		const bool dev = flags & GPLE_IO_DEVICE; // applies to Xs / mean only; the training set is small and host-side
+		Scratch Xt(ctx), yd(ctx), T(ctx), b(ctx), xs(ctx), o(ctx);
+		int n = 0;
+		GPLE_TRY(nlml_solve(ctx, x, X, y, N, Xt, yd, T, b, &n));
+		const double* xs_dev = Xs;
+		double* o_dev = mean;
+		if (!dev)
+		{
+			GPLE_HIP(ctx, xs.get(2 * M));
+			GPLE_HIP(ctx, o.get(M));
+			GPLE_HIP(ctx, copy_in(st, xs.p, Xs, 2 * M, false));
+			xs_dev = xs.p, o_dev = o.p;
+		}
+		GPLE_HIP(ctx, launch_nlml_predict(st, xs_dev, static_cast<int>(M), Xt.p, static_cast<int>(N), b.p, x, o_dev));
+		if (!dev) GPLE_HIP(ctx, copy_out(st, mean, o.p, M, false));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		return GPLE_OK;
 	}
 }

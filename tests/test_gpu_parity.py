@@ -188,3 +188,23 @@ def test_loose_function_complex_value(gpu, oracle):
     g = load_golden("complex_a")
     val, _ = gpu.loose_function(g["theta"], g["X"], g["y"], g["Xv"], g["tv"], want_grad=False)
     assert abs(val - (g["error"] + g["v_error"])) <= 1e-9 * abs(val)
+
+
+def test_nlml_value_gradient_and_prediction(gpu, oracle):
+    """test/gpr.cpp:499-532 (NLML + trace gradient, incl. the reference's half-gradient on the two kernel weights) and
+    :654-706 (mean-only predict without the noise kernel) against the oracle and a numpy evaluation."""
+    X, y, Xs = parity.synthetic_real(150, 300, 61)
+    x = np.array([0.1, 1.2, 1.0 / 0.8, 1.0 / 0.7])
+    vg, gg = gpu.nlml(x, X, y)
+    vo, go = oracle.nlml(x, X, y)
+    assert abs(vg - vo) <= 1e-9 * abs(vo)
+    assert np.abs(gg - go).max() <= 1e-7 * np.abs(go).max()
+    v0, _ = gpu.nlml(x, X, y, want_grad=False)
+    assert v0 == vg
+    d0 = x[2] * (X[:, None, 0] - X[None, :, 0])
+    d1 = x[3] * (X[:, None, 1] - X[None, :, 1])
+    Kn = x[1] ** 2 * np.exp(-0.5 * (d0 ** 2 + d1 ** 2)) + x[0] ** 2 * np.eye(len(X))
+    ref = 0.5 * y @ np.linalg.solve(Kn, y) + np.log(np.diag(np.linalg.cholesky(Kn))).sum()
+    assert abs(vg - ref) <= 1e-9 * abs(ref)
+    mg, mo = gpu.nlml_predict(x, X, y, Xs), oracle.nlml_predict(x, X, y, Xs)
+    assert np.abs(mg - mo).max() <= 1e-9 * np.abs(mo).max()
