@@ -134,6 +134,11 @@ struct gple_ctx: gple::Ctx
 
 namespace
 {
+	// per-fit device scalar block (doubles) and offsets into the context's pinned host block
+	constexpr int SDEV_N = 512;        // [0] s, [1..15] base sums, [16..28] real derivative sums, [31] info, [32..39] complex error derivative,
+	                                   // [64..108] complex purity quadratic forms (5 kernels x 9), [128..287] aux dots (5 x 8 x 4)
+	constexpr int HS_PRED_ERR = 512, HS_PRED_DERIV = 520, HS_NLML = 540;
+
 	// pooled buffer with scope lifetime
 	struct Scratch
 	{
@@ -191,10 +196,13 @@ struct FitCommon
 	double* W = nullptr;    // n_total^2, lazy
 	double* dv = nullptr;   // derivatives of v over the parameters, [nparam][n_total] (GPLE_CALC_DERIVATIVE fits only)
 	double sf = 1.0;        // real kernel: magnitude (needed unsquared by the derivative formulas)
+	double s0 = 1.0;        // complex kernel: global magnitude
+	DSpecSet dspec[6];      // complex kernel: derivative blocks of the parameters 1..6 (zero-initialised = inactive)
 	double* sdev = nullptr; // [0] rescale factor, [1..] raw sums, [31] info (as int)
 	double s_host = 0.0;
 	SEParamSet ps{};
 	double self = 0.0; // k(x*, x*)
+	FitCommon() { std::memset(dspec, 0, sizeof(dspec)); }
 	std::mutex lazy_mu;
 
 	~FitCommon()
@@ -257,7 +265,7 @@ namespace
 		GPLE_HIP(ctx, e);
 		f->w = ctx->acquire(static_cast<size_t>(nt) * 8, &e);
 		GPLE_HIP(ctx, e);
-		f->sdev = ctx->acquire(32 * 8, &e);
+		f->sdev = ctx->acquire(SDEV_N * 8, &e);
 		GPLE_HIP(ctx, e);
 		if (f->is_complex)
 		{
@@ -274,7 +282,7 @@ namespace
 		GPLE_HIP(ctx, u.get(nt));
 
 		GPLE_HIP(ctx, hipMemsetAsync(f->Xt, 0, 2 * static_cast<size_t>(Np) * 8, st));
-		GPLE_HIP(ctx, hipMemsetAsync(f->sdev, 0, 32 * 8, st));
+		GPLE_HIP(ctx, hipMemsetAsync(f->sdev, 0, SDEV_N * 8, st));
 		GPLE_HIP(ctx, copy_in(st, f->Xt, X, 2 * N, dev));
 		GPLE_HIP(ctx, copy_in(st, ytmp.p, y, ylen, dev));
 		GPLE_HIP(ctx, launch_prep_labels(st, ytmp.p, y_stride, f->is_complex ? 1 : 0, f->N, Np, f->ys, f->sdev));
@@ -340,6 +348,165 @@ namespace
 			GPLE_HIP(ctx, launch_quadform(st, f->Xt, f->N, k1, dv + 3 * static_cast<size_t>(nt), f->v, -1, qpart.p, f->sdev + 28));
 		}
 		return GPLE_OK;
+	}
+
+	struct ComplexAux
+	{
+		double sC, lC[2];
+		SEParam k[5]; // purity auxiliary kernels R', I', C', RC, IC (complex_kernel.cpp:287-356)
+		double lRC[2], lIC[2];
+	};
+	ComplexAux complex_aux(const double* th)
+	{
+		const double sR = th[1], lR0 = th[2], lR1 = th[3], sI = th[4], lI0 = th[5], lI1 = th[6];
+		ComplexAux a;
+		const double ss0 = lR0 * lR0 + lI0 * lI0, ss1 = lR1 * lR1 + lI1 * lI1;
+		a.sC = std::sqrt(sR * sI * ((2.0 * lR0 * lI0 / ss0) * (2.0 * lR1 * lI1 / ss1))); // complex_kernel.cpp:144-157
+		a.lC[0] = std::sqrt(ss0 / 2.0), a.lC[1] = std::sqrt(ss1 / 2.0);
+		auto mixed = [](double m1, double a0, double a1, double mb, double b0, double b1) { // complex_kernel.cpp:206-219
+			const double prod = (0.5 * (1.0 / (a0 * a0) + 1.0 / (b0 * b0))) * (0.5 * (1.0 / (a1 * a1) + 1.0 / (b1 * b1)));
+			const double m = m1 * mb / std::sqrt(std::sqrt(prod));
+			return make_se(m * m, 0.0, std::sqrt(a0 * a0 + b0 * b0), std::sqrt(a1 * a1 + b1 * b1));
+		};
+		a.k[0] = purity_aux(sR, lR0, lR1);
+		a.k[1] = purity_aux(sI, lI0, lI1);
+		a.k[2] = purity_aux(a.sC, a.lC[0], a.lC[1]);
+		a.k[3] = mixed(sR, lR0, lR1, a.sC, a.lC[0], a.lC[1]);
+		a.k[4] = mixed(sI, lI0, lI1, a.sC, a.lC[0], a.lC[1]);
+		a.lRC[0] = a.k[3].l0, a.lRC[1] = a.k[3].l1, a.lIC[0] = a.k[4].l0, a.lIC[1] = a.k[4].l1;
+		return a;
+	}
+	// derivative blocks dC_p (p = 1..6) of the reference's dK / dK~ (complex_kernel.cpp:20-132), without the s^2 factor (sic)
+	void build_dspecs(const double* th, DSpecSet* out)
+	{
+		const ComplexAux a = complex_aux(th);
+		const double sR = th[1], sI = th[4];
+		const double lR[2] = {th[2], th[3]}, lI[2] = {th[5], th[6]};
+		const double aR = sR * sR, aI = sI * sI, aC = a.sC * a.sC;
+		auto spec = [](double amp, double c0, double c1, const double* l, int dim) { return DSpec{amp, c0, c1, l[0], l[1], dim, 1}; };
+		std::memset(out, 0, 6 * sizeof(DSpecSet));
+		out[0].b[0] = spec(aR, 2.0 / sR, 0.0, lR, 0); // d/d sR: dC_xx = 2 KR / sR, dC_xy = KC / sR
+		out[0].b[1] = spec(aC, 1.0 / sR, 0.0, a.lC, 0);
+		out[3].b[2] = spec(aI, 2.0 / sI, 0.0, lI, 0); // d/d sI: dC_yy = 2 KI / sI, dC_xy = KC / sI
+		out[3].b[1] = spec(aC, 1.0 / sI, 0.0, a.lC, 0);
+		for (int d = 0; d < 2; ++d)
+		{
+			out[1 + d].b[0] = spec(aR, 0.0, 1.0, lR, d); // d/d lR_d: dC_xx = DR_d
+			out[1 + d].b[1] = spec(aC, 1.0 / lR[d] - lR[d] / (a.lC[d] * a.lC[d]), 0.5 * lR[d] / a.lC[d], a.lC, d);
+			out[4 + d].b[2] = spec(aI, 0.0, 1.0, lI, d); // d/d lI_d: dC_yy = DI_d
+			out[4 + d].b[1] = spec(aC, 1.0 / lI[d] - lI[d] / (a.lC[d] * a.lC[d]), 0.5 * lI[d] / a.lC[d], a.lC, d);
+		}
+	}
+
+	// TrainingComplexKernel derivative members (complex_kernel.cpp:379-590); raw sums land in sdev[32..39], [64..108], [128..287]
+	int complex_fit_derivatives(gple_ctx* ctx, FitCommon* f, const double* th, unsigned flags)
+	{
+		hipStream_t st = ctx->stream;
+		const int nt = f->n_total, Np = f->Np;
+		const size_t n2 = static_cast<size_t>(nt) * nt;
+		const double s0 = th[0], sn = th[7];
+		GPLE_TRY(ensure_inverse(f));
+		hipError_t e;
+		f->dv = ctx->acquire(8 * static_cast<size_t>(nt) * 8, &e);
+		GPLE_HIP(ctx, e);
+		Scratch D(ctx), C(ctx), part(ctx), tvec(ctx), dwd(ctx), dwx(ctx);
+		GPLE_HIP(ctx, D.get(n2));
+		GPLE_HIP(ctx, C.get(n2));
+		GPLE_HIP(ctx, part.get(static_cast<size_t>(nt / 256) * nt));
+		GPLE_HIP(ctx, tvec.get(nt));
+		GPLE_HIP(ctx, dwd.get(8 * static_cast<size_t>(nt)));
+		GPLE_HIP(ctx, dwx.get(8 * static_cast<size_t>(Np)));
+		double* dw = f->dv;
+		// global magnitude: dC = 2 C / s  ->  dM = -2 M / s
+		GPLE_HIP(ctx, launch_scale(st, f->v, -2.0 / s0, nt, dw));
+		GPLE_HIP(ctx, launch_scale(st, f->w, -2.0 / s0, nt, dwd.p));
+		GPLE_HIP(ctx, launch_scale(st, f->wx, -2.0 / s0, Np, dwx.p));
+		// noise: dK = 2 sn I, dK~ = 0 (complex_kernel.cpp:49-56, 129)  ->  dC = sn I  ->  dM = -sn M M
+		GPLE_HIP(ctx, launch_gemv(st, f->W, nt, nt, f->v, -sn, part.p, dw + 7 * static_cast<size_t>(nt)));
+		GPLE_HIP(ctx, launch_coldot(st, f->W, nt, f->W, nt, nt, 0, -sn, dwd.p + 7 * static_cast<size_t>(nt)));
+		GPLE_HIP(ctx, launch_coldot(st, f->W, nt, f->W, nt, nt, Np, -sn, dwx.p + 7 * static_cast<size_t>(Np)));
+		for (int ip = 1; ip <= 6; ++ip)
+		{
+			GPLE_HIP(ctx, launch_typed_deriv_gram(st, f->Xt, f->N, Np, nt, f->dspec[ip - 1], D.p));
+			GPLE_HIP(ctx, launch_gemv(st, D.p, nt, nt, f->v, 1.0, part.p, tvec.p));
+			GPLE_HIP(ctx, launch_gemv(st, f->W, nt, nt, tvec.p, -1.0, part.p, dw + static_cast<size_t>(ip) * nt));
+			GemmDesc g{};
+			g.A = D.p, g.lda = nt, g.B = f->W, g.ldb = nt, g.C = C.p, g.ldc = nt;
+			g.M = nt, g.N = nt, g.K = nt, g.batch = 1, g.alpha = 1.0, g.beta = 0.0, g.krange = K_FULL, g.lower_only = 0;
+			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
+			GPLE_HIP(ctx, launch_gemm(st, g, (nt / 128) * (nt / 128) >= 256 ? 128 : 64));
+			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, C.p, nt, nt, 0, -1.0, dwd.p + static_cast<size_t>(ip) * nt));
+			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, C.p, nt, nt, Np, -1.0, dwx.p + static_cast<size_t>(ip) * Np));
+		}
+		GPLE_HIP(ctx, launch_complex_deriv_sums(st, f->v, f->w, f->wx, dw, dwd.p, dwx.p, f->N, Np, f->sdev + 32));
+		if (flags & GPLE_CALC_AVERAGE)
+		{
+			const ComplexAux a = complex_aux(th);
+			const size_t g64 = (static_cast<size_t>(f->N) + 63) / 64, g256 = (static_cast<size_t>(f->N) + 255) / 256;
+			Scratch qpart(ctx), mpart(ctx), ga(ctx), gb(ctx);
+			GPLE_HIP(ctx, qpart.get(9 * g64 * g64));
+			GPLE_HIP(ctx, mpart.get(2 * g256 * g256 * 256));
+			GPLE_HIP(ctx, ga.get(g256 * 256));
+			GPLE_HIP(ctx, gb.get(g256 * 256));
+			const double *wr = f->v, *wi = f->v + Np;
+			for (int x = 0; x < 5; ++x)
+			{
+				GPLE_HIP(ctx, launch_multi_quadform(st, f->Xt, f->N, a.k[x], wr, wi, qpart.p, f->sdev + 64 + 9 * x));
+				GPLE_HIP(ctx, launch_aux_matvec(st, f->Xt, f->N, a.k[x], wr, wi, mpart.p, ga.p, gb.p));
+				GPLE_HIP(ctx, launch_aux_dots(st, ga.p, gb.p, dw, f->N, Np, nt, f->sdev + 128 + 32 * x));
+			}
+		}
+		return GPLE_OK;
+	}
+
+	// complex_kernel.cpp:475-590 from the raw sums (weights w = 2 v, so every quadratic form carries 1/4)
+	void complex_purity_derivative(const double* th, const double* h, double s, double* out8)
+	{
+		const ComplexAux a = complex_aux(th);
+		const double sR = th[1], sI = th[4];
+		const double lR[2] = {th[2], th[3]}, lI[2] = {th[5], th[6]};
+		const double GlobalFactor = (2.0 * M_PI) * 2.0 * M_PI; // :497 — no magnitude^4 here (reference quirk, :584 vs :370)
+		auto Q = [&](int x, int pair, int var) { return h[64 + 9 * x + 3 * pair + var]; };
+		auto Dd = [&](int x, int ip, int q) { return h[128 + 32 * x + 4 * ip + q]; };
+		for (int ip = 0; ip < 8; ++ip)
+		{
+			double c0[5] = {0, 0, 0, 0, 0}, c1[5] = {0, 0, 0, 0, 0};
+			int d = 0;
+			if (ip == 1)
+				c0[0] = 4.0 / sR, c0[2] = 2.0 / sR, c0[3] = 3.0 / sR, c0[4] = 1.0 / sR; // :525-529
+			else if (ip == 2 || ip == 3)
+			{
+				d = ip - 2;
+				const double l = lR[d], roc2 = l / (a.lC[d] * a.lC[d]);
+				c0[0] = 1.0 / l, c1[0] = std::sqrt(2.0);                                                                 // :534
+				c0[2] = 2.0 / l - 3.0 * roc2 / 2.0, c1[2] = 1.0 / std::sqrt(2.0) * (l / a.lC[d]);                          // :536-537
+				c0[3] = (2.0 / l - roc2 / 2.0) - 1.5 * (l / a.lRC[d]) / a.lRC[d], c1[3] = 1.5 * (l / a.lRC[d]);             // :538-539
+				c0[4] = (1.0 / l - roc2 / 2.0) - (l / a.lIC[d]) / 2.0 / a.lIC[d], c1[4] = (l / a.lIC[d]) / 2.0;             // :540-541
+			}
+			else if (ip == 4)
+				c0[1] = 4.0 / sI, c0[2] = 2.0 / sI, c0[3] = 1.0 / sI, c0[4] = 3.0 / sI; // :548-552
+			else if (ip == 5 || ip == 6)
+			{
+				d = ip - 5;
+				const double l = lI[d], ioc2 = l / (a.lC[d] * a.lC[d]);
+				c0[1] = 1.0 / l, c1[1] = std::sqrt(2.0);                                                                 // :558
+				c0[2] = 2.0 / l - 3.0 * ioc2 / 2.0, c1[2] = 1.0 / std::sqrt(2.0) * (l / a.lC[d]);                          // :559-560
+				c0[3] = (1.0 / l - ioc2 / 2.0) - (l / a.lRC[d]) / 2.0 / a.lRC[d], c1[3] = (l / a.lRC[d]) / 2.0;             // :561-562
+				c0[4] = (2.0 / l - ioc2 / 2.0) - 1.5 * (l / a.lIC[d]) / a.lIC[d], c1[4] = 1.5 * (l / a.lIC[d]);             // :563-564
+			}
+			auto dX = [&](int x, int pair) { return c0[x] * Q(x, pair, 0) + c1[x] * Q(x, pair, 1 + d); };
+			const double k1c[3] = {1.0, 1.0, 2.0};
+			double T1 = 0.0, T2 = 0.0;
+			for (int x = 0; x < 3; ++x)
+			{
+				T1 += k1c[x] * (Dd(x, ip, 0) + Dd(x, ip, 1)); // Re(v^H K1 dv)
+				T2 += k1c[x] * (dX(x, 0) + dX(x, 1));         // Re(v^H K1' v)
+			}
+			const double T3 = (Dd(0, ip, 0) - Dd(1, ip, 0)) - (Dd(0, ip, 1) - Dd(1, ip, 1)) + 2.0 * (Dd(3, ip, 2) + Dd(4, ip, 2))
+				+ 2.0 * (Dd(3, ip, 3) + Dd(4, ip, 3));                                                      // Re(v^T K2 dv)
+			const double T4 = (dX(0, 0) - dX(1, 0)) - (dX(0, 1) - dX(1, 1)) + 2.0 * 2.0 * (dX(3, 2) + dX(4, 2)); // Re(v^T K2' v)
+			out8[ip] = 0.25 * (2.0 * T1 + T2 + 2.0 * T3 + T4) * GlobalFactor / (s * s); // :580-584
+		}
 	}
 
 	template <typename S>
@@ -465,7 +632,7 @@ extern "C"
 			}
 			c->owns_stream = true;
 		}
-		if (hipHostMalloc(reinterpret_cast<void**>(&c->host_scalars), 64 * sizeof(double)) != hipSuccess)
+		if (hipHostMalloc(reinterpret_cast<void**>(&c->host_scalars), 2 * SDEV_N * sizeof(double)) != hipSuccess)
 		{
 			if (c->owns_stream) (void)hipStreamDestroy(c->stream);
 			delete c;
@@ -606,7 +773,7 @@ extern "C"
 				status = real_fit_derivatives(ctx, f, sf, l0, l1, sn, flags);
 				if (status != GPLE_OK) e = hipErrorUnknown;
 			}
-			if (e == hipSuccess) e = hipMemcpyAsync(ctx->host_scalars, f->sdev, 32 * 8, hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess) e = hipMemcpyAsync(ctx->host_scalars, f->sdev, SDEV_N * 8, hipMemcpyDeviceToHost, st);
 			timer_stop(ctx, GPLE_TIMER_FIT);
 			if (e == hipSuccess) e = hipStreamSynchronize(st);
 			timer_collect(ctx);
@@ -735,7 +902,7 @@ extern "C"
 		}
 		if (M == 0) return GPLE_OK;
 		const bool want_deriv = (flags & GPLE_CALC_DERIVATIVE) && labels;
-		if (want_deriv && (!f->dv || f->is_complex)) return GPLE_ERR_STATE; // needs a fit built with GPLE_CALC_DERIVATIVE
+		if (want_deriv && !f->dv) return GPLE_ERR_STATE; // needs a fit built with GPLE_CALC_DERIVATIVE
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
@@ -762,8 +929,10 @@ extern "C"
 		a.T = f->T, a.ldt = f->n_total, a.v = f->v, a.q = q.p, a.mu = mu.p, a.ps = f->ps;
 		if (want_deriv)
 		{
-			GPLE_HIP(ctx, dacc.get(7 * static_cast<size_t>(m_rows)));
+			GPLE_HIP(ctx, dacc.get((cplx ? 15 : 7) * static_cast<size_t>(m_rows)));
 			a.dv = f->dv, a.dacc = dacc.p;
+			a.complex_deriv = cplx ? 1 : 0;
+			if (cplx) std::memcpy(a.dspec, f->dspec, sizeof(a.dspec));
 		}
 		int chunk_rows = 0;
 		Scratch kstar(ctx);
@@ -809,13 +978,17 @@ extern "C"
 		if (labels)
 		{
 			GPLE_HIP(ctx, launch_sum(st, err_part, nblk, err_part + nblk));
-			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 32, err_part + nblk, 8, hipMemcpyDeviceToHost, st));
+			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_PRED_ERR, err_part + nblk, 8, hipMemcpyDeviceToHost, st));
 		}
 		if (want_deriv)
 		{
-			GPLE_HIP(ctx, dpart.get(4 * static_cast<size_t>(nblk) + 4));
-			GPLE_HIP(ctx, launch_predict_deriv_finish_real(st, dacc.p, m_rows, q.p, Mi, f->self, f->sf, f->sdev, lab_dev, dpart.p, dpart.p + 4 * nblk));
-			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 40, dpart.p + 4 * nblk, 4 * 8, hipMemcpyDeviceToHost, st));
+			GPLE_HIP(ctx, dpart.get(8 * static_cast<size_t>(nblk) + 8));
+			if (cplx)
+				GPLE_HIP(ctx, launch_predict_deriv_finish_complex(st, dacc.p, m_rows, Mh, q.p, Mi, f->self, f->s0, f->sdev, lab_dev, dpart.p,
+								  dpart.p + 8 * nblk));
+			else
+				GPLE_HIP(ctx, launch_predict_deriv_finish_real(st, dacc.p, m_rows, q.p, Mi, f->self, f->sf, f->sdev, lab_dev, dpart.p, dpart.p + 8 * nblk));
+			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_PRED_DERIV, dpart.p + 8 * nblk, 8 * 8, hipMemcpyDeviceToHost, st));
 		}
 		if (!dev)
 		{
@@ -831,9 +1004,9 @@ extern "C"
 			GPLE_HIP(ctx, hipStreamSynchronize(st));
 			timer_collect(ctx);
 		}
-		if (labels && scalars) scalars->error = ctx->host_scalars[32];
+		if (labels && scalars) scalars->error = ctx->host_scalars[HS_PRED_ERR];
 		if (want_deriv && scalars)
-			for (int ip = 0; ip < 4; ++ip) scalars->error_derivative[ip] = ctx->host_scalars[40 + ip];
+			for (int ip = 0; ip < (cplx ? 8 : 4); ++ip) scalars->error_derivative[ip] = ctx->host_scalars[HS_PRED_DERIV + ip];
 		return GPLE_OK;
 	}
 
@@ -850,7 +1023,6 @@ extern "C"
 	{
 		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 19)) return GPLE_ERR_BAD_ARG;
 		*out = nullptr;
-		if (flags & GPLE_CALC_DERIVATIVE) return GPLE_ERR_STATE; // TODO(round 1): derivative path
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		gple_complex_fit* f = new (std::nothrow) gple_complex_fit;
@@ -869,6 +1041,8 @@ extern "C"
 		f->ps.p[1] = make_se(m2 * (sC * sC), 0.0, lC0, lC1);
 		f->ps.p[2] = make_se(m2 * (sI * sI), (sn * sn) / (2.0 * sI * sI), lI0, lI1);
 		f->self = m2 * (sR * sR * (1.0 + 0.0) + sI * sI * (1.0 + 0.0) + sn * sn * 1.0); // complex_kernel.cpp:632
+		f->s0 = s0;
+		build_dspecs(theta, f->dspec);
 		hipStream_t st = ctx->stream;
 		int status = fit_common(ctx, f, X, y, 2, N, flags);
 		double purity_sums[6] = {0, 0, 0, 0, 0, 0};
@@ -896,11 +1070,16 @@ extern "C"
 				const double* bs[6] = {wr, wi, wr, wi, wi, wi};
 				for (int q = 0; q < 6 && e == hipSuccess; ++q) e = launch_quadform(st, f->Xt, f->N, ks[q], as[q], bs[q], -1, part.p, f->sdev + 8 + q);
 			}
-			if (e == hipSuccess) e = hipMemcpyAsync(ctx->host_scalars, f->sdev, 32 * 8, hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess && (flags & GPLE_CALC_DERIVATIVE))
+			{
+				status = complex_fit_derivatives(ctx, f, theta, flags);
+				if (status != GPLE_OK) e = hipErrorUnknown;
+			}
+			if (e == hipSuccess) e = hipMemcpyAsync(ctx->host_scalars, f->sdev, SDEV_N * 8, hipMemcpyDeviceToHost, st);
 			timer_stop(ctx, GPLE_TIMER_FIT);
 			if (e == hipSuccess) e = hipStreamSynchronize(st);
 			timer_collect(ctx);
-			if (e != hipSuccess) status = record_hip_error(ctx, e, "complex fit reductions", __LINE__);
+			if (e != hipSuccess && status == GPLE_OK) status = record_hip_error(ctx, e, "complex fit reductions", __LINE__);
 		}
 		if (status != GPLE_OK)
 		{
@@ -931,6 +1110,12 @@ extern "C"
 			const double qf = 0.25 * (2.0 * purity_sums[0] + 2.0 * purity_sums[1] + 2.0 * (purity_sums[2] + purity_sums[3])
 				+ 4.0 * (purity_sums[4] + purity_sums[5]));
 			sc.purity = ThisTimeFactor * qf / (s * s); // :373
+		}
+		if (flags & GPLE_CALC_DERIVATIVE)
+		{
+			if (flags & GPLE_CALC_ERROR)
+				for (int ip = 0; ip < 8; ++ip) sc.error_derivative[ip] = h[32 + ip];
+			if (flags & GPLE_CALC_AVERAGE) complex_purity_derivative(theta, h, s, sc.purity_derivative);
 		}
 		if (scalars) *scalars = sc;
 		*out = f;
@@ -1001,7 +1186,16 @@ extern "C"
 			GPLE_HIP(ctx, hipGetLastError());
 			GPLE_HIP(ctx, hipMemcpyAsync(dst, tmp.p, 2 * N * 8, kind, st));
 			break;
-		case GPLE_C_INVLBL_DERIV: return GPLE_ERR_STATE;
+		case GPLE_C_INVLBL_DERIV:
+			if (!f->dv) return GPLE_ERR_STATE;
+			GPLE_HIP(ctx, tmp.get(16 * N));
+			for (int ip = 0; ip < 8; ++ip)
+			{
+				hipLaunchKernelGGL(halve_pair_kernel, dim3((N + 255) / 256), blk, 0, st, f->dv + static_cast<size_t>(ip) * nt, (int)N, Np, tmp.p + 2 * ip * N);
+				GPLE_HIP(ctx, hipGetLastError());
+			}
+			GPLE_HIP(ctx, hipMemcpyAsync(dst, tmp.p, 16 * N * 8, kind, st));
+			break;
 		default: return GPLE_ERR_BAD_ARG;
 		}
 		GPLE_HIP(ctx, hipStreamSynchronize(st));
@@ -1039,14 +1233,15 @@ extern "C"
 		}
 		else
 		{
-			if (grad) return GPLE_ERR_STATE; // TODO(round 2): complex derivative path on the device
 			gple_complex_fit_scalars sc;
 			gple_complex_fit* fit = nullptr;
 			GPLE_TRY(gple_complex_fit_create(ctx, x, X, y, N, flags, &sc, &fit));
-			const int st = gple_complex_predict(ctx, fit, X_extra, M_extra, 0, y_extra, nullptr, nullptr, nullptr, &ps);
+			const int st = gple_complex_predict(ctx, fit, X_extra, M_extra, flags & GPLE_CALC_DERIVATIVE, y_extra, nullptr, nullptr, nullptr, &ps);
 			gple_complex_fit_release(fit);
 			GPLE_TRY(st);
 			result = sc.error + (M_extra ? ps.error : 0.0);
+			if (grad)
+				for (int i = 0; i < 8; ++i) grad[i] = sc.error_derivative[i] + (M_extra ? ps.error_derivative[i] : 0.0);
 		}
 		// make_normal, opt.cpp:420-431
 		auto make_normal = [](double& d) {
@@ -1111,11 +1306,11 @@ extern "C"
 			GPLE_HIP(ctx, lauum_full(st, T.p, n, W.p, n, n));
 			GPLE_HIP(ctx, launch_nlml_grad(st, Xt.p, static_cast<int>(N), W.p, n, b.p, x, part.p, out.p + 1));
 		}
-		GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 48, out.p, 5 * 8, hipMemcpyDeviceToHost, st));
+		GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_NLML, out.p, 5 * 8, hipMemcpyDeviceToHost, st));
 		GPLE_HIP(ctx, hipStreamSynchronize(st));
-		*value = ctx->host_scalars[48];
+		*value = ctx->host_scalars[HS_NLML];
 		if (grad)
-			for (int i = 0; i < 4; ++i) grad[i] = ctx->host_scalars[49 + i];
+			for (int i = 0; i < 4; ++i) grad[i] = ctx->host_scalars[HS_NLML + 1 + i];
 		return GPLE_OK;
 	}
 

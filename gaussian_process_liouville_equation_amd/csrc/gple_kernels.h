@@ -42,6 +42,36 @@ namespace gple
 	hipError_t launch_quadform(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, int fdim, double* part,
 		double* out);
 
+	// ---- complex derivative path (gple_cderiv.hip): everything in the real [Re; Im] embedding ------------------------
+	// One block of a derivative matrix: amp * G(l) * (c0 + c1 * ((x_d - x'_d)/l_d)^2 / l_d); active == 0 -> zero block.
+	struct DSpec
+	{
+		double amp, c0, c1;
+		double l0, l1;
+		int dim, active;
+	};
+	// blocks indexed by type_a + type_b: 0 = Re-Re, 1 = Re-Im (both off-diagonal blocks), 2 = Im-Im
+	struct DSpecSet
+	{
+		DSpec b[3];
+	};
+	// dC (n x n, padded with zeros) of the typed training set
+	hipError_t launch_typed_deriv_gram(hipStream_t s, const double* Xt, int N, int Np, int n, DSpecSet spec, double* D);
+	// out[ip] (ip = 0..7) = TrainingComplexKernel::ErrorDerivatives (complex_kernel.cpp:444-474) from the embedded quantities:
+	// w (weights, n), wd (diag M, n), wx (diag of the Re-Im block, Np) and their derivatives dw (8 x n), dwd (8 x n), dwx (8 x Np)
+	hipError_t launch_complex_deriv_sums(hipStream_t s, const double* w, const double* wd, const double* wx, const double* dw, const double* dwd,
+		const double* dwx, int N, int Np, double* out8);
+	// nine sums of one generated kernel X = amp G(l): out[3 * pair + var], pair in {(a,a), (b,b), (a,b)}, var in {1, f_0, f_1}
+	hipError_t launch_multi_quadform(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, double* part, double* out9);
+	// ya = X a, yb = X b for the generated kernel X (N x N); part: 2 * ceil(N/256) * N doubles
+	hipError_t launch_aux_matvec(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, double* part, double* ya,
+		double* yb);
+	// out[4 * ip + q] = (ga.dw_x, gb.dw_y, ga.dw_y, gb.dw_x)[q] for ip = 0..7 with dw_x = dw[ip*n .. ], dw_y = dw[ip*n + Np ..]
+	hipError_t launch_aux_dots(hipStream_t s, const double* ga, const double* gb, const double* dw, int N, int Np, int n, double* out32);
+	// PredictiveComplexKernel::ErrorDerivatives (complex_kernel.cpp:648-668) from the 15 accumulator planes of the derivative pass
+	hipError_t launch_predict_deriv_finish_complex(hipStream_t s, const double* acc, int m_rows, int m_split, const double* q, int M, double self,
+		double s0, const double* s_dev, const double* labels, double* part, double* out8);
+
 	// ---- derivative path (gple_deriv.hip) ------------------------------------------------------------------------
 	// D0, D1 (n x n, ld = n, padded with zeros): dK/dl_d of the training Gram, zero diagonal (kernel.cpp:123-157, 190)
 	hipError_t launch_deriv_gram(hipStream_t s, const double* Xt, int N, int n, SEParam p, double* D0, double* D1);
@@ -86,8 +116,12 @@ namespace gple
 		const double* T;
 		long ldt;
 		const double* v; // n_total weights (K^-1 y in the typed basis)
-		const double* dv; // derivative pass (real GP): 4 x n_total derivatives of v, or nullptr
-		double* dacc;     // derivative pass: 7 x m_rows accumulators [K* v, K* dv_0..3, (dK*/dl_0) v, (dK*/dl_1) v]
+		const double* dv; // derivative pass: nparam x n_total derivatives of v (real: 4, complex embedding: 8), or nullptr
+		double* dacc;     // derivative pass: accumulator planes of m_rows each
+		                  //   real:    7 = [K* v, K* dv_0..3, (dK*/dl_0) v, (dK*/dl_1) v]
+		                  //   complex: 15 = [c w, c dw_0..7, dc_1..6 w]
+		int complex_deriv;      // 1: use dspec (complex embedding)
+		DSpecSet dspec[6];      // derivative blocks of the parameters 1..6 (sub-kernel magnitudes and lengths)
 		double* q;       // m_rows: || T k*_m ||^2
 		double* mu;      // m_rows: k*_m . v
 		SEParamSet ps;

@@ -72,7 +72,9 @@ namespace gple
 		// One thread per row, blockIdx.y selects the k-range; the training point of each k is a scalar load.
 		// DERIV (real GP only): also accumulates K* dv_ip (ip = 0..3) and (dK*/dl_d) v (d = 0, 1) per row for
 		// PredictiveKernel::ErrorDerivatives (kernel.cpp:524-542); mu_part then holds 7 planes of GEN_KSPLIT x m_rows.
-		template <bool DERIV>
+		// DERIV = 2 (complex GP in the [Re; Im] embedding): 15 planes [c w, c dw_0..7, dc_1..6 w] for
+		// PredictiveComplexKernel::ErrorDerivatives (complex_kernel.cpp:648-668); dc_p comes from a.dspec[p - 1].
+		template <int DERIV>
 		__global__ void __launch_bounds__(128) kstar_gen_kernel(const PredictArgs a, int row0, int rows, double* __restrict__ Ks,
 			double* __restrict__ mu_part)
 		{
@@ -85,7 +87,10 @@ namespace gple
 			const int kper = a.n_total / GEN_KSPLIT; // multiple of 32 (n_total is a multiple of 256)
 			const int kbeg = blockIdx.y * kper;
 			double mu = 0.0;
-			double dacc[6] = {0, 0, 0, 0, 0, 0};
+			constexpr int NACC = DERIV == 2 ? 14 : 6;
+			double dacc[NACC];
+#pragma unroll
+			for (int ip = 0; ip < NACC; ++ip) dacc[ip] = 0.0;
 			double* __restrict__ out = Ks + r + static_cast<long>(kbeg) * rows;
 			for (int k0 = kbeg; k0 < kbeg + kper; k0 += 4)
 			{
@@ -106,7 +111,21 @@ namespace gple
 					const double delta = (xm == xk && pm == pkv) ? n2 : 0.0; // delta_kernel: exact equality, kernel.cpp:26
 					const double val = valid ? amp * (g + delta) : 0.0;
 					mu = fma(val, a.v[k], mu);
-					if constexpr (DERIV)
+					if constexpr (DERIV == 2)
+					{
+#pragma unroll
+						for (int ip = 0; ip < 8; ++ip) dacc[ip] = fma(val, a.dv[static_cast<long>(ip) * a.n_total + k], dacc[ip]);
+						const double gw = valid ? g * a.v[k] : 0.0;
+						const double f0 = d0 * d0 * rl0, f1 = d1 * d1 * rl1;
+#pragma unroll
+						for (int ip = 0; ip < 6; ++ip)
+						{
+							const DSpec& sp = a.dspec[ip].b[type_m + type_k];
+							const double fac = sp.active ? sp.amp * (sp.c0 + sp.c1 * (sp.dim == 0 ? f0 : f1)) : 0.0;
+							dacc[8 + ip] = fma(gw, fac, dacc[8 + ip]);
+						}
+					}
+					else if constexpr (DERIV == 1)
 					{
 #pragma unroll
 						for (int ip = 0; ip < 4; ++ip) dacc[ip] = fma(val, a.dv[static_cast<long>(ip) * a.n_total + k], dacc[ip]);
@@ -120,9 +139,9 @@ namespace gple
 				out += 4L * rows;
 			}
 			mu_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = mu;
-			if constexpr (DERIV)
+			if constexpr (DERIV != 0)
 #pragma unroll
-				for (int ip = 0; ip < 6; ++ip) mu_part[(static_cast<long>(ip + 1) * GEN_KSPLIT + blockIdx.y) * a.m_rows + gm] = dacc[ip];
+				for (int ip = 0; ip < NACC; ++ip) mu_part[(static_cast<long>(ip + 1) * GEN_KSPLIT + blockIdx.y) * a.m_rows + gm] = dacc[ip];
 		}
 
 		// q[row] = sum_n ( sum_{k <= n} K*(row, k) T(n, k) )^2 for one chunk of rows
@@ -253,7 +272,7 @@ namespace gple
 		if (rows < static_cast<size_t>(BM)) rows = BM;
 		if (rows > static_cast<size_t>(a.m_rows)) rows = a.m_rows;
 		*chunk_rows = static_cast<int>(rows);
-		return rows * a.n_total + static_cast<size_t>(GEN_KSPLIT) * a.m_rows * (a.dv ? 7 : 1);
+		return rows * a.n_total + static_cast<size_t>(GEN_KSPLIT) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1);
 	}
 
 	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows)
@@ -266,15 +285,17 @@ namespace gple
 		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
 		{
 			const int rows = a.m_rows - row0 < chunk_rows ? a.m_rows - row0 : chunk_rows;
-			if (a.dv) hipLaunchKernelGGL(kstar_gen_kernel<true>, dim3(rows / 128, GEN_KSPLIT), dim3(128), 0, s, a, row0, rows, Ks, mu_part);
-			else hipLaunchKernelGGL(kstar_gen_kernel<false>, dim3(rows / 128, GEN_KSPLIT), dim3(128), 0, s, a, row0, rows, Ks, mu_part);
+			const dim3 ggrid(rows / 128, GEN_KSPLIT);
+			if (a.dv && a.complex_deriv) hipLaunchKernelGGL(kstar_gen_kernel<2>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
+			else if (a.dv) hipLaunchKernelGGL(kstar_gen_kernel<1>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
+			else hipLaunchKernelGGL(kstar_gen_kernel<0>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
 			chunk_timer_start(ctx);
 			hipLaunchKernelGGL(rownorm_kernel, dim3(rows / BM), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
 			chunk_timer_stop(ctx);
 		}
 		// a.mu receives plane 0 (the mean); with derivatives a.dacc receives all 7 planes (plane 0 = the mean again)
 		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, a.mu);
-		if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 7), dim3(256), 0, s, mu_part, a.m_rows, a.dacc);
+		if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, a.complex_deriv ? 15 : 7), dim3(256), 0, s, mu_part, a.m_rows, a.dacc);
 		return hipGetLastError();
 	}
 } // namespace gple

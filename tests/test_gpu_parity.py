@@ -17,7 +17,7 @@ def test_real_fixture(gpu, name):
 
 @pytest.mark.parametrize("name,tol", parity.COMPLEX_FIXTURES)
 def test_complex_fixture(gpu, name, tol):
-    parity.check_complex_case(gpu, load_golden(name), deriv=False, tol=tol)
+    parity.check_complex_case(gpu, load_golden(name), deriv=True, tol=tol)
 
 
 @pytest.mark.parametrize("name", parity.REAL_FIXTURES)
@@ -184,10 +184,26 @@ def test_loose_function_real_matches_fixture_and_oracle(gpu, oracle):
     assert abs(v0 - vg) <= 1e-12 * abs(vg)
 
 
-def test_loose_function_complex_value(gpu, oracle):
+def test_loose_function_complex(gpu, oracle):
     g = load_golden("complex_a")
     val, _ = gpu.loose_function(g["theta"], g["X"], g["y"], g["Xv"], g["tv"], want_grad=False)
     assert abs(val - (g["error"] + g["v_error"])) <= 1e-9 * abs(val)
+    val2, grad = gpu.loose_function(g["theta"], g["X"], g["y"], g["Xv"], g["tv"])
+    ref = g["error_derivative"] + g["v_error_derivative"]
+    assert abs(val2 - val) <= 1e-12 * abs(val)
+    assert np.abs(grad - ref).max() <= 1e-8 * np.abs(ref).max()
+    # larger case against the oracle
+    X, yr, _ = parity.synthetic_real(120, 1, 71)
+    y = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0))
+    rng = np.random.default_rng(72)
+    Xe = X[rng.integers(0, len(X), 3 * len(X))] + rng.normal(0, [0.5, 0.5], size=(3 * len(X), 2))
+    re = np.exp(-0.5 * (((Xe[:, 0] + 10.0) / 0.7086) ** 2 + ((Xe[:, 1] - 14.112) / 0.7056) ** 2)) / (2 * np.pi * 0.7086 * 0.7056)
+    ye = 0.5 * re * np.exp(0.5j * (Xe[:, 0] + 10.0))
+    theta = [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05]
+    vg, gg = gpu.loose_function(theta, X, y, Xe, ye)
+    vo, go = oracle.loose_function(theta, X, y, Xe, ye)
+    assert abs(vg - vo) <= 1e-7 * abs(vo)
+    assert np.abs(gg - go).max() <= 1e-6 * np.abs(go).max()
 
 
 def test_nlml_value_gradient_and_prediction(gpu, oracle):
