@@ -27,6 +27,22 @@ namespace gple
 		// A (global, column-major, lda): in = SPD block (lower used), out = L (lower), strictly upper zeroed.
 		// Tinv (global, ldt): out = L^-1 (lower), strictly upper zeroed.
 		constexpr int LR = NB + 2; // LDS row stride (doubles): 16-byte aligned rows, rows 4 banks apart
+		__device__ __forceinline__ double readlane_f64(double v, int lane)
+		{
+			const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+			return __hiloint2double(hi, lo);
+		}
+		// 1/sqrt(d) to full precision: hardware estimate + two Newton steps (a lone wave pays the full latency of every fp64
+		// instruction, and sqrt + divide cost ~40 of them per column)
+		__device__ __forceinline__ double rsqrt_newton(double d)
+		{
+			double r = __builtin_amdgcn_rsq(d);
+			r = r * fma(-0.5 * d * r, r, 1.5);
+			r = r * fma(-0.5 * d * r, r, 1.5);
+			return r;
+		}
+		// The block is a single wave; the __syncthreads() below cost next to nothing at run time but are what keeps hipcc from
+		// hoisting the ~2000 LDS broadcasts of the unrolled loops and spilling kilobytes per lane (measured: 7.8 KB without).
 		__global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Tinv, long ldt,
 			int* __restrict__ info, int j0)
 		{
@@ -37,16 +53,23 @@ namespace gple
 #pragma unroll
 			for (int j = 0; j < NB; ++j) a[j] = A[i + static_cast<long>(j) * lda]; // coalesced: lanes = consecutive rows
 			bool bad = false;
+			double my_rinv = 0.0; // 1 / L(i,i), kept by lane i
 #pragma unroll
 			for (int k = 0; k < NB; ++k)
 			{
-				const double d = __shfl(a[k], k);
-				bad = bad || !(d > 0.0);
-				if (bad && i == 0) atomicCAS(info, 0, j0 + k + 1); // first offending column wins (info starts at 0)
-				const double sd = sqrt(d);
-				const double l = (i == k) ? sd : a[k] / sd;
+				const double d = readlane_f64(a[k], k);
+				if (!bad && !(d > 0.0))
+				{
+					bad = true;
+					if (i == 0) atomicCAS(info, 0, j0 + k + 1); // first offending column wins (info starts at 0)
+				}
+				const double r = rsqrt_newton(d); // NaN for d <= 0: propagates, like sqrt of a negative pivot
+				double sd = d * r;
+				sd = fma(fma(-sd, sd, d), 0.5 * r, sd); // sqrt(d), correctly rounded up to the last bit
+				const double l = (i == k) ? sd : a[k] * r;
 				a[k] = (i >= k) ? l : 0.0;
 				col[i] = l;
+				my_rinv = (i == k) ? r : my_rinv;
 				__syncthreads();
 #pragma unroll
 				for (int j = k + 1; j < NB; ++j) a[j] = fma(-l, col[j], a[j]);
@@ -56,11 +79,13 @@ namespace gple
 			for (int j = 0; j < NB; ++j)
 			{
 				A[i + static_cast<long>(j) * lda] = a[j];
-				Ls[i * LR + j] = a[j];
+				Ls[i * LR + j] = (j == i) ? my_rinv : a[j]; // the diagonal slot carries the reciprocal (a second LDS array for it
+				                                             // makes hipcc hoist 64 loads and spill)
 			}
 			__syncthreads();
-			// lane j: column j of X.  x[i] = (delta_ij - sum_{k=j}^{i-1} L(i,k) x[k]) / L(i,i); entries above the diagonal are 0,
-			// so the sum may start at k = 0 for every lane.
+			// lane j: column j of X = L^-1.  x[r] = (delta_rj - sum_{k<r} L(r,k) x[k]) / L(r,r); entries above the diagonal are 0,
+			// so the sum may start at k = 0 for every lane.  (A right-looking sweep with independent FMAs per step would
+			// shorten the dependency chains, but hipcc then spills 6.6 KB per lane.)
 			double x[NB];
 			const int j = threadIdx.x;
 #pragma unroll
@@ -69,7 +94,7 @@ namespace gple
 				double s = (r == j) ? 1.0 : 0.0;
 #pragma unroll
 				for (int k = 0; k < r; ++k) s = fma(-Ls[r * LR + k], x[k], s);
-				x[r] = (r >= j) ? s / Ls[r * LR + r] : 0.0;
+				x[r] = (r >= j) ? s * Ls[r * LR + r] : 0.0;
 			}
 			__syncthreads();
 			// transpose through LDS for coalesced stores: Ls[c][r] <- X(r, c)
