@@ -21,15 +21,18 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {  # name: (N, G)
-    "C1": (256, 128),
-    "C2": (1024, 256),
-    "C4r": (4096, 512),  # one real element of C4 (north-star target size)
+WORKLOADS = {  # name: (N, G, kernel)
+    "C1": (256, 128, "real"),
+    "C2": (1024, 256, "real"),      # BASELINE.json configs[1]: the default
+    "C3": (2048, 256, "complex"),   # configs[2]: off-diagonal density-matrix element
+    "C4r": (4096, 512, "real"),     # one real element of C4 = the north-star target size
+    "C4c": (4096, 512, "complex"),  # the complex element of C4
+    "C5r": (8192, 1024, "real"),    # one real element of C5
 }
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak; measured 78.4 with v_mfma_f64_16x16x4_f64
 
 
-def synthetic(N, G, seed):
+def synthetic(N, G, seed, kernel="real"):
     rng = np.random.Generator(np.random.PCG64(seed))
     x0, p0, sx, sp = -10.0, 14.112, 0.7086, 0.7056
     X = rng.normal([x0, p0], [sx, sp], size=(N, 2))
@@ -39,6 +42,9 @@ def synthetic(N, G, seed):
     ps = (p0 - np.pi / (2 * dx)) + (np.pi / dx / G) * np.arange(G)
     gx, gp = np.meshgrid(xs, ps, indexing="ij")  # point index = ix * G + ip (input.cpp:37-70)
     grid = np.ascontiguousarray(np.stack([gx.ravel(), gp.ravel()], axis=1))
+    if kernel == "complex":  # complex labels and the reference's initial complex parameters (opt.cpp:306-332)
+        y = 0.5 * y * np.exp(0.5j * (X[:, 0] - x0))
+        return X, y, grid, np.array([1.0, 1.0, sx, sp, 1.0, sx, sp, 1e-2])
     return X, y, grid, np.array([1.0, sx, sp, 1e-2])
 
 
@@ -66,9 +72,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    N, G = WORKLOADS[args.workload]
+    N, G, kernel = WORKLOADS[args.workload]
+    cplx = kernel == "complex"
     M = G * G
-    X, y, grid, theta = synthetic(N, G, 20240607 + 1)
+    X, y, grid, theta = synthetic(N, G, 20240607 + 1, kernel)
     # contiguous grid slice of this rank (padded to equal length so that all_gather_into_tensor applies)
     per = (M + world - 1) // world
     lo, hi = min(M, rank * per), min(M, (rank + 1) * per)
@@ -77,26 +84,34 @@ def main():
     api = pkg.open_api(local_rank, stream=stream.cuda_stream)  # the library runs on torch's current stream
     api.enable_timing(True)
     dX = torch.from_numpy(X).cuda()
-    dy = torch.from_numpy(y).cuda()
+    dy = torch.from_numpy(np.ascontiguousarray(y).view(np.float64) if cplx else y).cuda()
     dgrid = torch.from_numpy(grid[lo:hi].copy()).cuda()
-    out_local = torch.zeros(3, per, dtype=torch.float64, device="cuda")
-    out_full = torch.zeros(world * 3, per, dtype=torch.float64, device="cuda") if world > 1 else None
+    # rows: mean, variance, cut-off mean (real: 1 + 1 + 1, complex: 2 + 1 + 2 doubles per point)
+    out_local = torch.zeros(5 if cplx else 3, per, dtype=torch.float64, device="cuda")
+    out_full = torch.zeros(world * out_local.shape[0], per, dtype=torch.float64, device="cuda") if world > 1 else None
     dp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))
     th = np.ascontiguousarray(theta)
-    sc, ps = c.RealFitScalars(), c.PredictScalars()
+    sc, ps = (c.ComplexFitScalars() if cplx else c.RealFitScalars()), c.PredictScalars()
     flags = c.CALC_ERROR | c.CALC_AVERAGE | c.IO_DEVICE
+    thp = th.ctypes.data_as(C.POINTER(C.c_double))
+    # complex outputs are interleaved (re, im) pairs: rows 0-1 / 3-4 of out_local viewed as one buffer of 2 * per doubles
+    o_mean, o_var, o_cut = (out_local[0:2], out_local[2], out_local[3:5]) if cplx else (out_local[0], out_local[1], out_local[2])
 
     def step():
         h = C.c_void_p()
-        st = api.lib.gple_real_fit_create(api.ctx, th.ctypes.data_as(C.POINTER(C.c_double)), dp(dX), dp(dy), 0, N, flags, C.byref(sc), C.byref(h))
+        if cplx:
+            st = api.lib.gple_complex_fit_create(api.ctx, thp, dp(dX), dp(dy), N, flags, C.byref(sc), C.byref(h))
+        else:
+            st = api.lib.gple_real_fit_create(api.ctx, thp, dp(dX), dp(dy), 0, N, flags, C.byref(sc), C.byref(h))
         if st != 0:
             raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
-        st = api.lib.gple_real_predict(api.ctx, h, dp(dgrid), hi - lo, c.IO_DEVICE, None, dp(out_local[0]), dp(out_local[1]), dp(out_local[2]), C.byref(ps))
+        fn = api.lib.gple_complex_predict if cplx else api.lib.gple_real_predict
+        st = fn(api.ctx, h, dp(dgrid), hi - lo, c.IO_DEVICE, None, dp(o_mean), dp(o_var), dp(o_cut), C.byref(ps))
         if st != 0:
             raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
         if world > 1:
             dist.all_gather_into_tensor(out_full, out_local)
-        api.lib.gple_real_fit_release(h)
+        (api.lib.gple_complex_fit_release if cplx else api.lib.gple_real_fit_release)(h)
 
     for _ in range(args.warmup):
         step()
@@ -126,8 +141,20 @@ def main():
     m_local = hi - lo
     # algorithmic flops of the dominant kernel: triangular contraction ||T k*||^2 = N(N+1) flops per test point
     # (the reference's row * K^-1 * row^T form is 2 N^2 per point), split over the launches
-    flops = float(m_local) * N * (N + 1) / max(1.0, launches_per_step)
+    # complex GP = real GP on [Re; Im]: 2 typed rows per point against the 2N x 2N factor
+    nn, rows = (2 * N, 2 * m_local) if cplx else (N, m_local)
+    flops = float(rows) * nn * (nn + 1) / max(1.0, launches_per_step)
     achieved = flops / (pk_ms * 1e-3) / 1e12 if pk_ms > 0 else 0.0
+    # HBM traffic of one rownorm_kernel launch: PMC counters cannot be read from inside the run; the value committed under
+    # profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950 guide
+    # prescribes) is reported when it was taken on this workload at this GPU count
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if tj.get("workload") == args.workload and world == 1:
+            traffic = tj["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     result = {
         "metric": "GP fit+predict ms/step (N samples, M grid pts)",
         "value": round(ms_per_step, 4),
@@ -141,17 +168,17 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload}: N={N} samples, {G}x{G} grid (M={M}), real SE kernel, fit(error+average) + grid predict(mean,var,cutoff)",
+        "config": {"workload": f"{args.workload}: N={N} samples, {G}x{G} grid (M={M}), {kernel} SE kernel, fit(error+average) + grid predict(mean,var,cutoff)",
                    "N": N, "M": M, "parallelism": f"grid-sharded x{world}, replicated fit, RCCL all-gather" if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "kernel": "rownorm_kernel (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
                      "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
-                     "traffic": None, "kernel_ms": round(pk_ms, 4), "launches_per_step": launches_per_step,
+                     "traffic": traffic, "kernel_ms": round(pk_ms, 4), "launches_per_step": launches_per_step,
                      "algorithmic_flops_per_launch": flops,
-                     "reference_form_flops_per_launch": 2.0 * m_local * N * N / max(1.0, launches_per_step)},
+                     "reference_form_flops_per_launch": (32.0 if cplx else 2.0) * m_local * N * N / max(1.0, launches_per_step)},
         "phases_ms": {"fit_device": round(fit_total / max(1, fit_cnt), 4), "predict_device": round(pred_total / max(1, pred_cnt), 4),
                       "rownorm_kernel_per_step": round(pk_total / max(1, args.steps), 4)},
     }
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not cplx:
         from oracle import binding
         ora = binding.load()
         t0 = time.perf_counter()
