@@ -17,23 +17,16 @@ namespace gple
 	{
 		constexpr int NB = CHOL_NB; // 64
 
-		// One wave factors the NB x NB diagonal block and inverts the factor, register-resident:
-		//   Cholesky: lane i owns row i of the block (64 doubles in VGPRs); column k is scaled lane-locally, published
-		//             to LDS and broadcast back for the rank-1 update of the lane's row (fully unrolled, so every row
-		//             element stays a named register);
-		//   inverse : lane j owns column j of X = L^-1 and runs its own forward substitution; row i of L is an LDS
-		//             broadcast.
-		// ~2 x 2016 dependent FMAs with LDS broadcasts in between instead of 128 block-wide barrier rounds.
-		// A (global, column-major, lda): in = SPD block (lower used), out = L (lower), strictly upper zeroed.
-		// Tinv (global, ldt): out = L^-1 (lower), strictly upper zeroed.
 		constexpr int LR = NB + 2; // LDS row stride (doubles): 16-byte aligned rows, rows 4 banks apart
+		constexpr int PANEL_THREADS = 256;                           // 4 waves: 512 registers each (64 row elements + 64 broadcasts in flight)
+		constexpr int PANEL_ROWS = (PANEL_THREADS / 64 - 1) * 64;    // rows below the diagonal block per workgroup (192)
+
 		__device__ __forceinline__ double readlane_f64(double v, int lane)
 		{
 			const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
 			return __hiloint2double(hi, lo);
 		}
-		// 1/sqrt(d) to full precision: hardware estimate + two Newton steps (a lone wave pays the full latency of every fp64
-		// instruction, and sqrt + divide cost ~40 of them per column)
+		// 1/sqrt(d) to full precision: hardware estimate + two Newton steps (sqrt + divide cost ~40 fp64 instructions)
 		__device__ __forceinline__ double rsqrt_newton(double d)
 		{
 			double r = __builtin_amdgcn_rsq(d);
@@ -41,68 +34,91 @@ namespace gple
 			r = r * fma(-0.5 * d * r, r, 1.5);
 			return r;
 		}
-		// The block is a single wave; the __syncthreads() below cost next to nothing at run time but are what keeps hipcc from
-		// hoisting the ~2000 LDS broadcasts of the unrolled loops and spilling kilobytes per lane (measured: 7.8 KB without).
-		__global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Tinv, long ldt,
-			int* __restrict__ info, int j0)
+
+		// Panel factorisation: the 64 x 64 diagonal block is factored and, in the same sweep, applied to the rows below
+		// (P <- P L_jj^-T by substitution), one matrix row per lane with its 64 panel entries in registers.  Wave 0 of every
+		// workgroup owns the diagonal block — re-factored redundantly per workgroup, so workgroups never synchronise —
+		// waves 1..3 own 192 panel rows.  Per column: wave 0 publishes the pivot, every lane scales its entry, wave 0
+		// publishes the scaled column, every lane applies the rank-1 update to its row.
+		// A points at block (j0, j0); m = rows from j0 to the end of the matrix (multiple of 64).
+		__global__ void __launch_bounds__(PANEL_THREADS) potrf_panel_kernel(double* __restrict__ A, long lda, int m, int* __restrict__ info, int j0)
 		{
+			// No branches inside the column loop: control flow between the unrolled columns makes hipcc spill kilobytes per
+			// lane.  Stores that only wave 0 should make go to a dump slot for the other waves.
 			__shared__ __attribute__((aligned(16))) double col[NB];
-			__shared__ __attribute__((aligned(16))) double Ls[NB * LR];
-			const int i = threadIdx.x;
+			__shared__ __attribute__((aligned(16))) double pv[NB];
+			__shared__ double dump[PANEL_THREADS];
+			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const bool diag = w == 0;
+			const int row = diag ? lane : NB + blockIdx.x * PANEL_ROWS + (w - 1) * 64 + lane;
+			const bool valid = row < m;
+			double* const my_pv = diag ? &pv[lane] : &dump[threadIdx.x];
+			double* const my_col = diag ? &col[lane] : &dump[threadIdx.x];
 			double a[NB];
+			const double* __restrict__ src = A + (valid ? row : 0);
 #pragma unroll
-			for (int j = 0; j < NB; ++j) a[j] = A[i + static_cast<long>(j) * lda]; // coalesced: lanes = consecutive rows
-			bool bad = false;
-			double my_rinv = 0.0; // 1 / L(i,i), kept by lane i
+			for (int j = 0; j < NB; ++j) a[j] = src[static_cast<long>(j) * lda];
+			int first_bad = 0;
 #pragma unroll
 			for (int k = 0; k < NB; ++k)
 			{
-				const double d = readlane_f64(a[k], k);
-				if (!bad && !(d > 0.0))
-				{
-					bad = true;
-					if (i == 0) atomicCAS(info, 0, j0 + k + 1); // first offending column wins (info starts at 0)
-				}
-				const double r = rsqrt_newton(d); // NaN for d <= 0: propagates, like sqrt of a negative pivot
+				*my_pv = a[k];
+				__syncthreads();
+				const double d = pv[k];
+				first_bad = (first_bad == 0 && !(d > 0.0)) ? k + 1 : first_bad;
+				const double r = rsqrt_newton(d); // NaN for d <= 0: propagates, like the sqrt of a negative pivot
 				double sd = d * r;
-				sd = fma(fma(-sd, sd, d), 0.5 * r, sd); // sqrt(d), correctly rounded up to the last bit
-				const double l = (i == k) ? sd : a[k] * r;
-				a[k] = (i >= k) ? l : 0.0;
-				col[i] = l;
-				my_rinv = (i == k) ? r : my_rinv;
+				sd = fma(fma(-sd, sd, d), 0.5 * r, sd); // sqrt(d) with a correction step
+				const double lp = a[k] * r;
+				const double l = diag ? (lane == k ? sd : (lane > k ? lp : 0.0)) : lp;
+				a[k] = l;
+				*my_col = l;
 				__syncthreads();
 #pragma unroll
 				for (int j = k + 1; j < NB; ++j) a[j] = fma(-l, col[j], a[j]);
-				__syncthreads();
 			}
+			if (first_bad != 0 && threadIdx.x == 0 && blockIdx.x == 0) atomicCAS(info, 0, j0 + first_bad); // info starts at 0
+			if (valid && (!diag || blockIdx.x == 0))
+			{
+				double* __restrict__ dst = A + row;
+#pragma unroll
+				for (int j = 0; j < NB; ++j) dst[static_cast<long>(j) * lda] = a[j];
+			}
+		}
+
+		// Tinv_b = L_b^-1 for every 64 x 64 diagonal block b of the factor (one wave per block, all blocks in one launch):
+		// lane j owns column j of the inverse and runs its own forward substitution; row r of L is an LDS broadcast.
+		__global__ void __launch_bounds__(64) trinv_diag_kernel(const double* __restrict__ L, long ldl, double* __restrict__ T, long ldt)
+		{
+			__shared__ __attribute__((aligned(16))) double Ls[NB * LR];
+			const long off = static_cast<long>(blockIdx.x) * NB;
+			const double* __restrict__ Lb = L + off + off * ldl;
+			double* __restrict__ Tb = T + off + off * ldt;
+			const int i = threadIdx.x;
 #pragma unroll
 			for (int j = 0; j < NB; ++j)
 			{
-				A[i + static_cast<long>(j) * lda] = a[j];
-				Ls[i * LR + j] = (j == i) ? my_rinv : a[j]; // the diagonal slot carries the reciprocal (a second LDS array for it
-				                                             // makes hipcc hoist 64 loads and spill)
+				const double v = Lb[i + static_cast<long>(j) * ldl];
+				Ls[i * LR + j] = (j == i) ? 1.0 / v : v; // the diagonal slot carries the reciprocal
 			}
 			__syncthreads();
-			// lane j: column j of X = L^-1.  x[r] = (delta_rj - sum_{k<r} L(r,k) x[k]) / L(r,r); entries above the diagonal are 0,
-			// so the sum may start at k = 0 for every lane.  (A right-looking sweep with independent FMAs per step would
-			// shorten the dependency chains, but hipcc then spills 6.6 KB per lane.)
+			// x[r] = (delta_rj - sum_{k<r} L(r,k) x[k]) / L(r,r); entries above the diagonal are 0, so every lane may start at k = 0
 			double x[NB];
-			const int j = threadIdx.x;
 #pragma unroll
 			for (int r = 0; r < NB; ++r)
 			{
-				double s = (r == j) ? 1.0 : 0.0;
+				double s = (r == i) ? 1.0 : 0.0;
 #pragma unroll
 				for (int k = 0; k < r; ++k) s = fma(-Ls[r * LR + k], x[k], s);
-				x[r] = (r >= j) ? s * Ls[r * LR + r] : 0.0;
+				x[r] = (r >= i) ? s * Ls[r * LR + r] : 0.0;
 			}
 			__syncthreads();
 			// transpose through LDS for coalesced stores: Ls[c][r] <- X(r, c)
 #pragma unroll
-			for (int r = 0; r < NB; ++r) Ls[j * LR + r] = x[r];
+			for (int r = 0; r < NB; ++r) Ls[i * LR + r] = x[r];
 			__syncthreads();
 #pragma unroll
-			for (int c = 0; c < NB; ++c) Tinv[i + static_cast<long>(c) * ldt] = Ls[c * LR + i];
+			for (int c = 0; c < NB; ++c) Tb[i + static_cast<long>(c) * ldt] = Ls[c * LR + i];
 		}
 
 		// upper(i<j) = lower(j,i) for a full symmetric result
@@ -134,24 +150,22 @@ namespace gple
 		if (n % NB) return hipErrorInvalidValue;
 		for (int j0 = 0; j0 < n; j0 += NB)
 		{
-			hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, s, A + j0 + static_cast<long>(j0) * lda, lda,
-				T + j0 + static_cast<long>(j0) * ldt, ldt, info, j0);
-			const int m = n - j0 - NB;
-			if (m <= 0) break;
+			const int m = n - j0; // rows of the panel including the diagonal block
+			const int below = m - NB;
+			const int nwg = below > 0 ? (below + PANEL_ROWS - 1) / PANEL_ROWS : 1;
+			hipLaunchKernelGGL(potrf_panel_kernel, dim3(nwg), dim3(PANEL_THREADS), 0, s, A + j0 + static_cast<long>(j0) * lda, lda, m, info, j0);
+			if (below <= 0) break;
+			// trailing update: A22 -= P P^T (lower tiles)
 			double* P = A + (j0 + NB) + static_cast<long>(j0) * lda;
 			GemmDesc g{};
-			// panel: P <- P * inv(L_jj)^T   (in place: one 64-wide n-tile per workgroup covers the whole panel width)
-			g.A = P, g.lda = lda, g.B = T + j0 + static_cast<long>(j0) * ldt, g.ldb = ldt, g.C = P, g.ldc = lda;
-			g.M = m, g.N = NB, g.K = NB, g.batch = 1, g.alpha = 1.0, g.beta = 0.0, g.krange = K_FULL, g.lower_only = 0;
+			g.A = P, g.lda = lda, g.B = P, g.ldb = lda, g.C = A + (j0 + NB) + static_cast<long>(j0 + NB) * lda, g.ldc = lda;
+			g.M = below, g.N = below, g.K = NB, g.batch = 1, g.alpha = -1.0, g.beta = 1.0, g.krange = K_FULL, g.lower_only = 1;
 			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
-			hipError_t e = launch_gemm(s, g, 64);
-			if (e != hipSuccess) return e;
-			// trailing update: A22 -= P P^T (lower tiles)
-			g.A = P, g.B = P, g.ldb = lda, g.C = A + (j0 + NB) + static_cast<long>(j0 + NB) * lda;
-			g.M = m, g.N = m, g.K = NB, g.alpha = -1.0, g.beta = 1.0, g.lower_only = 1;
-			e = launch_gemm(s, g, pick_tile(m, m, 1) == 128 && m >= 2048 ? 128 : 64);
+			const hipError_t e = launch_gemm(s, g, pick_tile(below, below, 1) == 128 && below >= 2048 ? 128 : 64);
 			if (e != hipSuccess) return e;
 		}
+		// the 64 x 64 inverses are only the leaves of the merge tree: one batched launch, off the factorisation's critical path
+		hipLaunchKernelGGL(trinv_diag_kernel, dim3(n / NB), dim3(64), 0, s, A, lda, T, ldt);
 		return hipGetLastError();
 	}
 
