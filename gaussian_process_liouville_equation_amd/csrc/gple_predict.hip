@@ -24,6 +24,7 @@
 // the result columns (lane & 15) on the test row m, so the squared row sums stay lane-local.
 //
 // "Typed" rows/columns implement the complex GP as a real GP on [Re; Im] (see gple_kernels.h, SEParamSet).
+#include <cstdlib>
 #include <type_traits>
 
 #include "gple_kernels.h"
@@ -144,52 +145,61 @@ namespace gple
 				for (int ip = 0; ip < NACC; ++ip) mu_part[(static_cast<long>(ip + 1) * GEN_KSPLIT + blockIdx.y) * a.m_rows + gm] = dacc[ip];
 		}
 
-		// q[row] = sum_n ( sum_{k <= n} K*(row, k) T(n, k) )^2 for one chunk of rows
-		__global__ void __launch_bounds__(NTHREADS) rownorm_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T,
+		// q[row] = sum_n ( sum_{k <= n} K*(row, k) T(n, k) )^2 for one chunk of rows.
+		// WAVES waves x 16 rows per workgroup, K advances KB per barrier.  <8, 16>: one workgroup fills a CU (2 waves per
+		// SIMD); <4, 8>: two independent workgroups per CU cover each other's barrier / pipeline-fill bubbles (selected with
+		// GPLE_ROWNORM_VARIANT for A/B runs, default chosen in launch_predict_q).
+		template <int WAVES, int KB>
+		__global__ void __launch_bounds__(WAVES * 64, 8 / WAVES) rownorm_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T,
 			long ldt, int n_total, double* __restrict__ q)
 		{
-			__shared__ __attribute__((aligned(16))) double lds[2 * A_SLAB + 2 * B_SLAB];
+			constexpr int TM = WAVES * 16, NT = WAVES * 64;
+			constexpr int ASr = TM + 16;
+			constexpr int ASL = KB * ASr, BSL = KB * BS;
+			constexpr int NA = TM * KB / 2 / NT, NBv = BN * KB / 2 / NT; // double2 per thread and slab
+			static_assert(NA >= 1 && NBv >= 1, "tile too small for the thread count");
+			__shared__ __attribute__((aligned(16))) double lds[2 * ASL + 2 * BSL];
 			double* const As = lds;
-			double* const Bs = lds + 2 * A_SLAB;
+			double* const Bs = lds + 2 * ASL;
 			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
 			const int fk = lane >> 4, fr = lane & 15;
-			const int m0 = blockIdx.x * BM;
+			const int m0 = blockIdx.x * TM;
 			const int ntiles = n_total / BN;
 			double rsq = 0.0;
 
-			d2 areg[2], breg[4];
+			d2 areg[NA], breg[NBv];
 			auto load_ab = [&](int n0, int k0) {
 				const double* __restrict__ abase = Ks + m0 + static_cast<long>(k0) * rows;
 #pragma unroll
-				for (int qq = 0; qq < 2; ++qq)
+				for (int qq = 0; qq < NA; ++qq)
 				{
-					const int i = t + NTHREADS * qq;
-					const int r2 = (i & 63) * 2, k = i >> 6;
+					const int i = t + NT * qq;
+					const int r2 = (i % (TM / 2)) * 2, k = i / (TM / 2);
 					areg[qq] = *reinterpret_cast<const d2*>(abase + r2 + static_cast<long>(k) * rows);
 				}
 				const double* __restrict__ bbase = T + n0 + static_cast<long>(k0) * ldt;
 #pragma unroll
-				for (int qq = 0; qq < 4; ++qq)
+				for (int qq = 0; qq < NBv; ++qq)
 				{
-					const int i = t + NTHREADS * qq;
+					const int i = t + NT * qq;
 					const int r2 = (i & 127) * 2, k = i >> 7;
 					breg[qq] = *reinterpret_cast<const d2*>(bbase + r2 + static_cast<long>(k) * ldt);
 				}
 			};
 			auto store_ab = [&](int buf) {
-				double* __restrict__ sa = As + buf * A_SLAB;
+				double* __restrict__ sa = As + buf * ASL;
 #pragma unroll
-				for (int qq = 0; qq < 2; ++qq)
+				for (int qq = 0; qq < NA; ++qq)
 				{
-					const int i = t + NTHREADS * qq;
-					const int r2 = (i & 63) * 2, k = i >> 6;
-					*reinterpret_cast<d2*>(sa + k * AS + r2) = areg[qq];
+					const int i = t + NT * qq;
+					const int r2 = (i % (TM / 2)) * 2, k = i / (TM / 2);
+					*reinterpret_cast<d2*>(sa + k * ASr + r2) = areg[qq];
 				}
-				double* __restrict__ sb = Bs + buf * B_SLAB;
+				double* __restrict__ sb = Bs + buf * BSL;
 #pragma unroll
-				for (int qq = 0; qq < 4; ++qq)
+				for (int qq = 0; qq < NBv; ++qq)
 				{
-					const int i = t + NTHREADS * qq;
+					const int i = t + NT * qq;
 					const int r2 = (i & 127) * 2, k = i >> 7;
 					*reinterpret_cast<d2*>(sb + k * BS + r2) = breg[qq];
 				}
@@ -198,7 +208,7 @@ namespace gple
 			for (int jt = 0; jt < ntiles; ++jt)
 			{
 				const int n0 = jt * BN;
-				const int nk = (n0 + BN) / BK; // T(n,k) = 0 for k > n: k-slabs beyond the N-tile's last column are skipped
+				const int nk = (n0 + BN) / KB; // T(n,k) = 0 for k > n: k-slabs beyond the N-tile's last column are skipped
 				d4 acc[16];
 #pragma unroll
 				for (int j = 0; j < 16; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -211,13 +221,13 @@ namespace gple
 				// one k-step: prefetch slab s + 1, MFMAs of slab s against the column blocks j >= JMIN, commit the prefetch
 				auto kstep = [&](auto jmin_tag, int s) {
 					constexpr int JMIN = decltype(jmin_tag)::value;
-					if (s + 1 < nk) load_ab(n0, (s + 1) * BK);
-					const double* __restrict__ pa = As + (s & 1) * A_SLAB + w * 16 + fr;
-					const double* __restrict__ pb = Bs + (s & 1) * B_SLAB + fr;
+					if (s + 1 < nk) load_ab(n0, (s + 1) * KB);
+					const double* __restrict__ pa = As + (s & 1) * ASL + w * 16 + fr;
+					const double* __restrict__ pb = Bs + (s & 1) * BSL + fr;
 #pragma unroll
-					for (int kk = 0; kk < BK; kk += 4)
+					for (int kk = 0; kk < KB; kk += 4)
 					{
-						const double af = pa[(kk + fk) * AS];
+						const double af = pa[(kk + fk) * ASr];
 #pragma unroll
 						for (int h = JMIN; h < 16; h += 4)
 						{
@@ -233,12 +243,12 @@ namespace gple
 				};
 				// k-slabs below the diagonal N-tile and its first 64 columns see every column block; afterwards the column
 				// blocks left of the current k (T(n,k) = 0 for k > n) drop out, 64 columns at a time
-				const int nd = n0 / BK;
+				const int nd = n0 / KB, q64 = 64 / KB;
 				int s = 0;
-				for (; s < nd + 4; ++s) kstep(std::integral_constant<int, 0>{}, s);
-				for (; s < nd + 8; ++s) kstep(std::integral_constant<int, 4>{}, s);
-				for (; s < nd + 12; ++s) kstep(std::integral_constant<int, 8>{}, s);
-				for (; s < nd + 16; ++s) kstep(std::integral_constant<int, 12>{}, s);
+				for (; s < nd + q64; ++s) kstep(std::integral_constant<int, 0>{}, s);
+				for (; s < nd + 2 * q64; ++s) kstep(std::integral_constant<int, 4>{}, s);
+				for (; s < nd + 3 * q64; ++s) kstep(std::integral_constant<int, 8>{}, s);
+				for (; s < nd + 4 * q64; ++s) kstep(std::integral_constant<int, 12>{}, s);
 
 				// result element [n = 16 j + fk + 4 r][m = 16 w + fr]: the row index m is lane-local
 #pragma unroll
@@ -280,6 +290,10 @@ namespace gple
 		if (a.M <= 0) return hipSuccess;
 		if (a.m_rows % BM || a.n_total % BN || a.m_split % BM || a.n_split % BN || chunk_rows % BM || chunk_rows <= 0)
 			return hipErrorInvalidValue;
+		static const int variant = [] {
+			const char* e = getenv("GPLE_ROWNORM_VARIANT");
+			return e ? atoi(e) : 0;
+		}();
 		double* Ks = scratch;
 		double* mu_part = scratch + static_cast<size_t>(chunk_rows) * a.n_total;
 		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
@@ -290,7 +304,8 @@ namespace gple
 			else if (a.dv) hipLaunchKernelGGL(kstar_gen_kernel<1>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
 			else hipLaunchKernelGGL(kstar_gen_kernel<0>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
 			chunk_timer_start(ctx);
-			hipLaunchKernelGGL(rownorm_kernel, dim3(rows / BM), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
+			if (variant == 1) hipLaunchKernelGGL((rownorm_kernel<4, 8>), dim3(rows / 64), dim3(256), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
+			else hipLaunchKernelGGL((rownorm_kernel<8, 16>), dim3(rows / BM), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
 			chunk_timer_stop(ctx);
 		}
 		// a.mu receives plane 0 (the mean); with derivatives a.dacc receives all 7 planes (plane 0 = the mean again)

@@ -224,3 +224,47 @@ def test_nlml_value_gradient_and_prediction(gpu, oracle):
     assert abs(vg - ref) <= 1e-9 * abs(ref)
     mg, mo = gpu.nlml_predict(x, X, y, Xs), oracle.nlml_predict(x, X, y, Xs)
     assert np.abs(mg - mo).max() <= 1e-9 * np.abs(mo).max()
+
+
+@pytest.mark.parametrize("N", [2100, 4096])
+def test_large_fit_identities(gpu, N):
+    """Sizes that take the 128-tile MFMA GEMMs and an uneven merge tree (Np = 2304 -> 36 diagonal blocks; 4096 -> the
+    north-star size): K W = I and K v = y residuals, LOOCV error from the getters, variance range on scattered points."""
+    X, y, Xs = parity.synthetic_real(N, 3000, 20240607 + N)
+    theta = [1.0, 0.7086, 0.7056, 1e-2]
+    fit = gpu.real_fit(theta, X, y, 3)
+    assert fit.scalars["info"] == 0
+    K, W, v, ys = fit.get(c.R_KERNEL), fit.get(c.R_INVERSE), fit.get(c.R_INVLBL), fit.get(c.R_LABEL)
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    assert n1(K @ W - np.eye(N)) <= 50 * N * parity.EPS * n1(K) * n1(W)
+    assert np.abs(K @ v - ys).max() <= 50 * N * parity.EPS * (n1(K) * np.abs(v).max() + np.abs(ys).max())
+    assert np.abs(W - W.T).max() <= 1e-9 * np.abs(W).max()
+    assert abs(((v / np.diag(W)) ** 2).sum() - fit.scalars["error"]) <= 1e-9 * fit.scalars["error"]
+    assert np.abs(np.diag(W) - fit.get(c.R_INVERSE_DIAG)).max() <= 1e-9 * np.abs(np.diag(W)).max()
+    p = gpu.real_predict(fit, Xs)
+    kss = theta[0] ** 2 * (1 + theta[3] ** 2)
+    assert p["variance"].min() >= -1e-7 and p["variance"].max() <= kss + 1e-12
+    # mean and variance against numpy in the reference's form k W k^T on a few rows
+    Ks = gpu.real_gram(theta, Xs[:64], X, False)
+    assert np.abs(Ks @ v - p["prediction"][:64]).max() <= 1e-8 * np.abs(p["prediction"]).max()
+    assert np.abs((kss - np.einsum("ij,jk,ik->i", Ks, W, Ks)) - p["variance"][:64]).max() <= 1e-7
+
+
+def test_large_complex_fit_identities(gpu):
+    """complex element with n = 2 Np = 2560 (uneven merge tree in the embedded factorisation)"""
+    N = 1100
+    X, yr, Xs = parity.synthetic_real(N, 500, 99)
+    y = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0))
+    theta = [1.0, 1.0, 0.7086, 0.7056, 1.2, 0.8, 0.6, 1e-2]
+    fit = gpu.complex_fit(theta, X, y, 3)
+    assert fit.scalars["info"] == 0
+    K, Kt = fit.get(c.C_KERNEL), fit.get(c.C_PSEUDO)
+    P, Q, v, ys = fit.get(c.C_UPPER_LEFT), fit.get(c.C_LOWER_LEFT), fit.get(c.C_INVLBL), fit.get(c.C_LABEL)
+    # augmented system: [K Kt; Kt* K] [P; Q] = [I; 0]  and  K v + Kt conj(v) = y
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    scale = 50 * 2 * N * parity.EPS * (n1(K) + n1(Kt)) * (n1(P) + n1(Q))
+    assert n1(K @ P + Kt @ Q - np.eye(N)) <= scale
+    assert n1(Kt.conj() @ P + K @ Q) <= scale
+    assert np.abs(K @ v + Kt @ v.conj() - ys).max() <= 1e-7 * np.abs(ys).max()
+    p = gpu.complex_predict(fit, Xs)
+    assert np.all(np.isfinite(p["variance"])) and p["variance"].min() >= -1e-7
