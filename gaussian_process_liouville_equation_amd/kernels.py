@@ -475,3 +475,49 @@ def full_constraints(x, want_grad, params, api=None, num_pes=None):
         rows = [widen(ks.population_derivative()), widen(ks.total_energy_derivative(Energies)), list(ks.purity_derivative())]
         grad = [make_normal(float(d)) for r in rows for d in r]
     return [make_normal(r) for r in result], grad
+
+
+# ---- "next" row N1: batched replacement of the per-point DistributionFunction ---------------------------
+def predict_distribution(all_kernels, r, RowIndex, ColIndex):
+    """Batched form of main.cpp:75-101's `predict_distribution` lambda: the cut-off prediction of density-matrix element
+    (RowIndex, ColIndex) at every phase-space point of r (B, 2) in ONE predict call (the reference constructs one
+    PredictiveKernel per point, O(N^2) each, ~10^2 N times per tick: evolve.cpp:298, mc.cpp:158-172).
+    Returns a complex array (B,); zeros when the element has no kernel (main.cpp:86-88, 97-99)."""
+    r = np.atleast_2d(np.asarray(r, dtype=float))
+    k = all_kernels(RowIndex, ColIndex) if RowIndex != ColIndex else all_kernels(RowIndex)
+    if k is None or len(r) == 0:
+        return np.zeros(len(r), dtype=complex)
+    if RowIndex == ColIndex:
+        return PredictiveKernel(r, k, False).get_cutoff_prediction().astype(complex)
+    return PredictiveComplexKernel(r, k, False).get_cutoff_prediction()
+
+
+class DistributionBatcher:
+    """Gather - predict - scatter queue for the callers that evaluate the distribution point by point (evolve.cpp:184-372
+    asks for 8 back-propagated points per sample, mc.cpp:143-188 for one per Metropolis step): callers `request` points and
+    keep the returned ticket, `flush` runs one predict per density-matrix element, `result(ticket)` hands the values back."""
+
+    def __init__(self, all_kernels):
+        self.all_kernels = all_kernels
+        self._pending = {}   # (row, col) -> list of (ticket, points)
+        self._results = {}
+        self._next = 0
+
+    def request(self, r, RowIndex, ColIndex):
+        ticket = self._next
+        self._next += 1
+        self._pending.setdefault((RowIndex, ColIndex), []).append((ticket, np.atleast_2d(np.asarray(r, dtype=float))))
+        return ticket
+
+    def flush(self):
+        for (row, col), items in self._pending.items():
+            pts = np.concatenate([p for _, p in items], axis=0)
+            vals = predict_distribution(self.all_kernels, pts, row, col)
+            pos = 0
+            for ticket, p in items:
+                self._results[ticket] = vals[pos:pos + len(p)]
+                pos += len(p)
+        self._pending = {}
+
+    def result(self, ticket):
+        return self._results.pop(ticket)

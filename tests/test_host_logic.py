@@ -106,3 +106,23 @@ def test_objective_wrappers(oracle):
     assert abs(res[0] - (ga["population"] - 1.0)) < 1e-9 and len(cg) == 48
     res2, cg2 = K.diagonal_constraints(3, x[:4] + params[(1, 1)], True, (sets, [0.3, 0.7], 0.1, 1.0), api=oracle)
     assert len(res2) == 3 and len(cg2) == 24 and np.allclose(cg2[:4], ga["population_derivative"], rtol=1e-6, atol=1e-9)
+
+
+def test_batched_distribution_matches_pointwise(oracle):
+    """N1: the gather-predict-scatter queue returns what the reference's one-point lambda (main.cpp:75-101) returns"""
+    ga, gc, sets, params = _sets()
+    ks = K.TrainingKernels(params, sets, True, True, False, api=oracle)
+    rng = np.random.default_rng(3)
+    pts = ga["Xs"][:12]
+    batch = K.predict_distribution(ks, pts, 0, 0)
+    single = np.array([K.PredictiveKernel(p, ks(0), False).get_cutoff_prediction()[0] for p in pts])
+    assert np.allclose(batch.real, single, rtol=0, atol=1e-15) and np.all(batch.imag == 0)
+    assert np.all(K.predict_distribution(ks, pts, 1, 1) == 0)  # element without a kernel -> 0 (main.cpp:86-88)
+    q = K.DistributionBatcher(ks)
+    t1 = q.request(pts[:5], 0, 0)
+    t2 = q.request(gc["Xs"][:4], 1, 0)
+    t3 = q.request(pts[5:6], 0, 0)
+    q.flush()
+    assert np.allclose(q.result(t1), batch[:5]) and np.allclose(q.result(t3), batch[5:6])
+    ref = K.PredictiveComplexKernel(gc["Xs"][:4], ks(1, 0), False).get_cutoff_prediction()
+    assert np.allclose(q.result(t2), ref, rtol=0, atol=1e-15)
