@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1: nccl (= RCCL over xGMI, the default) or gloo (rehearsal of the "
+                         "multi-rank path on fewer GPUs than ranks; ranks then share devices and gather through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -68,9 +71,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
     N, G, kernel = WORKLOADS[args.workload]
     cplx = kernel == "complex"
@@ -81,7 +88,7 @@ def main():
     lo, hi = min(M, rank * per), min(M, (rank + 1) * per)
 
     stream = torch.cuda.current_stream()
-    api = pkg.open_api(local_rank, stream=stream.cuda_stream)  # the library runs on torch's current stream
+    api = pkg.open_api(dev, stream=stream.cuda_stream)  # the library runs on torch's current stream
     api.enable_timing(True)
     dX = torch.from_numpy(X).cuda()
     dy = torch.from_numpy(np.ascontiguousarray(y).view(np.float64) if cplx else y).cuda()
@@ -110,7 +117,12 @@ def main():
         if st != 0:
             raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
         if world > 1:
-            dist.all_gather_into_tensor(out_full, out_local)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(out_full, out_local)  # RCCL, ordered on the same stream as the kernels
+            else:
+                host = torch.empty(out_full.shape, dtype=out_full.dtype)
+                dist.all_gather_into_tensor(host, out_local.cpu())
+                out_full.copy_(host)
         (api.lib.gple_complex_fit_release if cplx else api.lib.gple_real_fit_release)(h)
 
     for _ in range(args.warmup):
@@ -128,9 +140,13 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # sanity of the gathered grid: every rank must now hold all M points (checked once, outside the timed region)
+        full = out_full.view(world, out_local.shape[0], per).permute(1, 0, 2).reshape(out_local.shape[0], world * per)[:, :M]
+        if not bool(torch.isfinite(full).all()):
+            raise RuntimeError("gathered prediction contains non-finite values")
     ms_per_step = 1e3 * elapsed / args.steps
 
     _, fit_total, fit_cnt = api.timing(0)

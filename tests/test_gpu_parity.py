@@ -268,3 +268,45 @@ def test_large_complex_fit_identities(gpu):
     assert np.abs(K @ v + Kt @ v.conj() - ys).max() <= 1e-7 * np.abs(ys).max()
     p = gpu.complex_predict(fit, Xs)
     assert np.all(np.isfinite(p["variance"])) and p["variance"].min() >= -1e-7
+
+
+def test_concurrent_predicts_on_one_fit(gpu):
+    """evolve.cpp:392-420 calls the predictors from TBB worker threads: predict must be thread-safe on a shared fit"""
+    import threading
+    X, y, Xs = parity.synthetic_real(300, 2000, 81)
+    fit = gpu.real_fit([1.0, 0.7086, 0.7056, 1e-2], X, y, 1)
+    ref = gpu.real_predict(fit, Xs)
+    out, errs = {}, []
+
+    def work(i):
+        try:
+            sl = slice(i * 500, (i + 1) * 500)
+            for _ in range(5):
+                out[i] = gpu.real_predict(fit, Xs[sl])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    for i in range(4):
+        sl = slice(i * 500, (i + 1) * 500)
+        assert np.array_equal(out[i]["prediction"], ref["prediction"][sl]) and np.array_equal(out[i]["variance"], ref["variance"][sl])
+
+
+def test_complex_edge_cases(gpu, oracle):
+    """single training point, empty test set, prediction at the training points (delta kernel in both typed blocks)"""
+    X, yr, Xs = parity.synthetic_real(30, 7, 91)
+    y = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0))
+    theta = [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.2]
+    fg, fo = gpu.complex_fit(theta, X, y, 3), oracle.complex_fit(theta, X, y, 3)
+    assert gpu.complex_predict(fg, np.zeros((0, 2)))["variance"].size == 0
+    pg, po = gpu.complex_predict(fg, X), oracle.complex_predict(fo, X)
+    assert np.abs(pg["variance"] - po["variance"]).max() <= 1e-10
+    assert np.abs(pg["prediction"] - po["prediction"]).max() <= 1e-10 * np.abs(po["prediction"]).max()
+    f1g, f1o = gpu.complex_fit(theta, X[:1], y[:1], 3), oracle.complex_fit(theta, X[:1], y[:1], 3)
+    for k in ("error", "purity", "magnitude"):
+        assert abs(f1g.scalars[k] - f1o.scalars[k]) <= 1e-12 * abs(f1o.scalars[k])
+    p1g, p1o = gpu.complex_predict(f1g, Xs), oracle.complex_predict(f1o, Xs)
+    assert np.abs(p1g["cutoff"] - p1o["cutoff"]).max() <= 1e-13 and np.abs(p1g["variance"] - p1o["variance"]).max() <= 1e-13
