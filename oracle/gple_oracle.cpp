@@ -1302,18 +1302,19 @@ extern "C"
 			Vec lab(M_extra);
 			for (size_t i = 0; i < M_extra; i++) lab[i] = y_extra[2 * i]; // ExtraTrainingLabel.real(), :451
 			real_predict(f, X_extra, M_extra, flags, lab.data(), nullptr, nullptr, nullptr, &ps);
-			result = f.sc.error + ps.error;
+			// an empty extra set contributes the empty sum, 0 (Eigen's .sum() over zero rows), not "no label"
+			result = f.sc.error + (M_extra ? ps.error : 0.0);
 			if (grad)
-				for (int i = 0; i < 4; i++) grad[i] = f.sc.error_derivative[i] + ps.error_derivative[i];
+				for (int i = 0; i < 4; i++) grad[i] = f.sc.error_derivative[i] + (M_extra ? ps.error_derivative[i] : 0.0);
 		}
 		else
 		{
 			oracle_complex_fit f;
 			complex_fit(f, x, X, y, N, flags);
 			complex_predict(f, X_extra, M_extra, flags, y_extra, nullptr, nullptr, nullptr, &ps);
-			result = f.sc.error + ps.error;
+			result = f.sc.error + (M_extra ? ps.error : 0.0);
 			if (grad)
-				for (int i = 0; i < 8; i++) grad[i] = f.sc.error_derivative[i] + ps.error_derivative[i];
+				for (int i = 0; i < 8; i++) grad[i] = f.sc.error_derivative[i] + (M_extra ? ps.error_derivative[i] : 0.0);
 		}
 		make_normal(result);
 		if (grad)
