@@ -7,6 +7,7 @@
 // tree of MFMA GEMMs, and only on request W = K^-1 = T^T T.  A non-positive pivot does not abort: sqrt() yields
 // NaN which propagates into every output, and *info records the first offending column (reference behaviour:
 // LDLT::info() is never checked, NaN/Inf are clamped later by opt.cpp:420-431).
+#include <utility>
 #include <vector>
 
 #include "gple_internal.h"
@@ -18,8 +19,8 @@ namespace gple
 		constexpr int NB = CHOL_NB; // 64
 
 		constexpr int LR = NB + 2; // LDS row stride (doubles): 16-byte aligned rows, rows 4 banks apart
-		constexpr int PANEL_THREADS = 256;                           // 4 waves: 512 registers each (64 row elements + 64 broadcasts in flight)
-		constexpr int PANEL_ROWS = (PANEL_THREADS / 64 - 1) * 64;    // rows below the diagonal block per workgroup (192)
+		constexpr int PANEL_THREADS = 128;          // wave 0: the diagonal block; wave 1: 64 panel rows
+		constexpr int PANEL_ROWS = PANEL_THREADS - 64; // rows below the diagonal block per workgroup
 
 		__device__ __forceinline__ double readlane_f64(double v, int lane)
 		{
@@ -35,48 +36,130 @@ namespace gple
 			return r;
 		}
 
+		// ---- broadcast reads of one scaled column, issued by hand -----------------------------------------------------------
+		// In the rank-1 update every lane needs the same 63-k column entries.  Left to itself hipcc keeps about three
+		// ds_read_b128 in flight there and exposes the LDS latency sixteen times per column (measured: 970 cycles per
+		// column, probes/panel_probe.hip).  The reads are therefore issued from inline asm in chunks of eight (16 entries),
+		// two chunks in flight, with explicit s_waitcnt; the "+v" operands of the wait tie the consumers to it.  LDS
+		// operations return in order, so compiler-issued LDS traffic in between can only make a wait longer, never too short.
+		typedef double v2f64 __attribute__((ext_vector_type(2)));
+		struct Chunk
+		{
+			v2f64 c[8];
+		};
+		template <int OFF>
+		__device__ __forceinline__ void lds_read8(Chunk& q, unsigned addr)
+		{
+			asm volatile("ds_read_b128 %0, %8 offset:%9\n"
+						 "ds_read_b128 %1, %8 offset:%9+16\n"
+						 "ds_read_b128 %2, %8 offset:%9+32\n"
+						 "ds_read_b128 %3, %8 offset:%9+48\n"
+						 "ds_read_b128 %4, %8 offset:%9+64\n"
+						 "ds_read_b128 %5, %8 offset:%9+80\n"
+						 "ds_read_b128 %6, %8 offset:%9+96\n"
+						 "ds_read_b128 %7, %8 offset:%9+112\n"
+						 : "=&v"(q.c[0]), "=&v"(q.c[1]), "=&v"(q.c[2]), "=&v"(q.c[3]), "=&v"(q.c[4]), "=&v"(q.c[5]), "=&v"(q.c[6]), "=&v"(q.c[7])
+						 : "v"(addr), "n"(OFF));
+		}
+		template <int N>
+		__device__ __forceinline__ void lds_wait(Chunk& q)
+		{
+			asm volatile("s_waitcnt lgkmcnt(%8)"
+						 : "+v"(q.c[0]), "+v"(q.c[1]), "+v"(q.c[2]), "+v"(q.c[3]), "+v"(q.c[4]), "+v"(q.c[5]), "+v"(q.c[6]), "+v"(q.c[7])
+						 : "n"(N));
+		}
+		// a[j] -= l * column[j] for the entries j > K of chunk C (entries 16 C .. 16 C + 15)
+		template <int K, int C>
+		__device__ __forceinline__ void apply_chunk(double (&a)[NB], const Chunk& q, double l)
+		{
+#pragma unroll
+			for (int i = 0; i < 8; ++i)
+			{
+				const int j = 16 * C + 2 * i;
+				if (j > K) a[j] = fma(-l, q.c[i].x, a[j]);
+				if (j + 1 > K) a[j + 1] = fma(-l, q.c[i].y, a[j + 1]);
+			}
+		}
+		template <int K>
+		__device__ __forceinline__ void rank1_update(double (&a)[NB], unsigned addr, double l)
+		{
+			constexpr int CF = (K + 1) / 16; // first chunk holding an entry > K
+			if constexpr (K + 1 < NB)
+			{
+				Chunk q0, q1;
+				lds_read8<CF * 128>(q0, addr);
+				if constexpr (CF + 1 < 4) lds_read8<(CF + 1) * 128>(q1, addr);
+				lds_wait<(CF + 1 < 4) ? 8 : 0>(q0);
+				apply_chunk<K, CF>(a, q0, l);
+				if constexpr (CF + 2 < 4) lds_read8<(CF + 2) * 128>(q0, addr);
+				if constexpr (CF + 1 < 4)
+				{
+					lds_wait<(CF + 2 < 4) ? 8 : 0>(q1);
+					apply_chunk<K, CF + 1>(a, q1, l);
+					if constexpr (CF + 3 < 4) lds_read8<(CF + 3) * 128>(q1, addr);
+				}
+				if constexpr (CF + 2 < 4)
+				{
+					lds_wait<(CF + 3 < 4) ? 8 : 0>(q0);
+					apply_chunk<K, CF + 2>(a, q0, l);
+				}
+				if constexpr (CF + 3 < 4)
+				{
+					lds_wait<0>(q1);
+					apply_chunk<K, CF + 3>(a, q1, l);
+				}
+			}
+		}
+
+		// One column of the panel sweep.  All waves run the same instruction stream (no branches: control flow between
+		// the unrolled columns makes hipcc spill kilobytes per lane); stores only wave 0 should make go to a dump slot.
+		template <int K>
+		__device__ __forceinline__ void panel_column(double (&a)[NB], double (*col)[NB + 2], double* dump, int lane, bool diag, int& first_bad)
+		{
+			double* const cb = &col[K & 1][0];
+			double* const my_col = diag ? &cb[lane] : &dump[threadIdx.x];
+			double* const my_r = (diag && lane == 0) ? &cb[NB] : &dump[threadIdx.x];
+			const double d = readlane_f64(a[K], K); // the pivot in wave 0; a harmless number in the other waves
+			first_bad = (first_bad == 0 && !(d > 0.0)) ? K + 1 : first_bad;
+			const double r0 = rsqrt_newton(d); // NaN for d <= 0: propagates, like the sqrt of a negative pivot
+			double sd = d * r0;
+			sd = fma(fma(-sd, sd, d), 0.5 * r0, sd); // sqrt(d) with a correction step
+			*my_col = lane == K ? sd : (lane > K ? a[K] * r0 : 0.0);
+			*my_r = r0;
+			__syncthreads(); // the only barrier of the column: col[] is double-buffered
+			const double r = cb[NB];
+			const double lp = a[K] * r;
+			const double l = diag ? (lane == K ? sd : (lane > K ? lp : 0.0)) : lp;
+			a[K] = l;
+			rank1_update<K>(a, static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) double*)cb)), l);
+		}
+		template <int... Ks>
+		__device__ __forceinline__ void panel_columns(double (&a)[NB], double (*col)[NB + 2], double* dump, int lane, bool diag, int& first_bad,
+			std::integer_sequence<int, Ks...>)
+		{
+			(panel_column<Ks>(a, col, dump, lane, diag, first_bad), ...);
+		}
+
 		// Panel factorisation: the 64 x 64 diagonal block is factored and, in the same sweep, applied to the rows below
 		// (P <- P L_jj^-T by substitution), one matrix row per lane with its 64 panel entries in registers.  Wave 0 of every
 		// workgroup owns the diagonal block — re-factored redundantly per workgroup, so workgroups never synchronise —
-		// waves 1..3 own 192 panel rows.  Per column: wave 0 publishes the pivot, every lane scales its entry, wave 0
-		// publishes the scaled column, every lane applies the rank-1 update to its row.
+		// wave 1 owns 64 panel rows.  Per column: wave 0 takes the pivot by readlane and publishes the scaled column with
+		// 1/L_kk next to it; after the barrier every lane scales its own entry and applies the rank-1 update to its row.
 		// A points at block (j0, j0); m = rows from j0 to the end of the matrix (multiple of 64).
 		__global__ void __launch_bounds__(PANEL_THREADS) potrf_panel_kernel(double* __restrict__ A, long lda, int m, int* __restrict__ info, int j0)
 		{
-			// No branches inside the column loop: control flow between the unrolled columns makes hipcc spill kilobytes per
-			// lane.  Stores that only wave 0 should make go to a dump slot for the other waves.
-			__shared__ __attribute__((aligned(16))) double col[NB];
-			__shared__ __attribute__((aligned(16))) double pv[NB];
+			__shared__ __attribute__((aligned(16))) double col[2][NB + 2];
 			__shared__ double dump[PANEL_THREADS];
 			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 			const bool diag = w == 0;
 			const int row = diag ? lane : NB + blockIdx.x * PANEL_ROWS + (w - 1) * 64 + lane;
 			const bool valid = row < m;
-			double* const my_pv = diag ? &pv[lane] : &dump[threadIdx.x];
-			double* const my_col = diag ? &col[lane] : &dump[threadIdx.x];
 			double a[NB];
 			const double* __restrict__ src = A + (valid ? row : 0);
 #pragma unroll
 			for (int j = 0; j < NB; ++j) a[j] = src[static_cast<long>(j) * lda];
 			int first_bad = 0;
-#pragma unroll
-			for (int k = 0; k < NB; ++k)
-			{
-				*my_pv = a[k];
-				__syncthreads();
-				const double d = pv[k];
-				first_bad = (first_bad == 0 && !(d > 0.0)) ? k + 1 : first_bad;
-				const double r = rsqrt_newton(d); // NaN for d <= 0: propagates, like the sqrt of a negative pivot
-				double sd = d * r;
-				sd = fma(fma(-sd, sd, d), 0.5 * r, sd); // sqrt(d) with a correction step
-				const double lp = a[k] * r;
-				const double l = diag ? (lane == k ? sd : (lane > k ? lp : 0.0)) : lp;
-				a[k] = l;
-				*my_col = l;
-				__syncthreads();
-#pragma unroll
-				for (int j = k + 1; j < NB; ++j) a[j] = fma(-l, col[j], a[j]);
-			}
+			panel_columns(a, col, dump, lane, diag, first_bad, std::make_integer_sequence<int, NB>{});
 			if (first_bad != 0 && threadIdx.x == 0 && blockIdx.x == 0) atomicCAS(info, 0, j0 + first_bad); // info starts at 0
 			if (valid && (!diag || blockIdx.x == 0))
 			{
