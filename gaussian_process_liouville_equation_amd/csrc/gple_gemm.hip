@@ -185,6 +185,128 @@ namespace gple
 					}
 		}
 
+		// The 64 x 64 tile for the latency-bound GEMMs of the fit (Cholesky trailing updates with K = 64, merge-tree levels
+		// with K = 64 .. 512 on a few dozen workgroups): with one slab of 16 in flight every k-step pays a full HBM/L2 round
+		// trip (measured 10.9 us for a K = 64 update whose MFMAs take 1.7 us).  Here four slabs are in flight: a 4-deep
+		// register prefetch feeding a 4-slab LDS ring, and the C tile of a beta != 0 update is requested up front as well.
+		template <bool AK, bool BKM, bool CT>
+		__global__ void __launch_bounds__(256, 2) gemm_f64_deep_kernel(const GemmDesc g)
+		{
+			constexpr int BM = 64, BN = 64, DEPTH = 4;
+			constexpr int WTM = BM / 2, WTN = BN / 2;
+			constexpr int TM = WTM / 16, TN = WTN / 16;
+			constexpr int AS = BM + LPAD, BS = BN + LPAD;
+			__shared__ __attribute__((aligned(16))) double lds[DEPTH * BK * AS + DEPTH * BK * BS];
+			double* const As = lds;
+			double* const Bs = lds + DEPTH * BK * AS;
+
+			const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+			const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+			if (g.lower_only && n0 >= m0 + BM) return;
+			int kb = 0, ke = g.K;
+			if (g.krange == K_GE_N) kb = n0;
+			else if (g.krange == K_LE_M) ke = min(g.K, m0 + BM);
+			else if (g.krange == K_GE_MAX_MN) kb = max(m0, n0);
+			kb = kb / BK * BK;
+			const int nk = (ke - kb + BK - 1) / BK;
+
+			const double* __restrict__ A = g.A + blockIdx.z * g.strideA;
+			const double* __restrict__ B = g.B + blockIdx.z * g.strideB;
+			double* __restrict__ C = g.C + blockIdx.z * g.strideC;
+			auto a_at = [&](int k) { return AK ? A + k + static_cast<long>(m0) * g.lda : A + m0 + static_cast<long>(k) * g.lda; };
+			auto b_at = [&](int k) { return BKM ? B + k + static_cast<long>(n0) * g.ldb : B + n0 + static_cast<long>(k) * g.ldb; };
+			const int fk = lane >> 4, fr = lane & 15;
+			auto c_index = [&](int i, int j, int r) -> long {
+				if constexpr (CT)
+				{
+					const int m = m0 + wm * WTM + i * 16 + fk + 4 * r, n = n0 + wn * WTN + j * 16 + fr;
+					return n + static_cast<long>(m) * g.ldc;
+				}
+				else
+				{
+					const int m = m0 + wm * WTM + i * 16 + fr, n = n0 + wn * WTN + j * 16 + fk + 4 * r;
+					return m + static_cast<long>(n) * g.ldc;
+				}
+			};
+
+			TileLoader<BM, AK> la[DEPTH];
+			TileLoader<BN, BKM> lb[DEPTH];
+#pragma unroll
+			for (int p = 0; p < DEPTH; ++p)
+				if (p < nk)
+				{
+					la[p].load(a_at(kb + p * BK), g.lda, t);
+					lb[p].load(b_at(kb + p * BK), g.ldb, t);
+				}
+			const double alpha = g.alpha, beta = g.beta;
+			double cold[TM][TN][4];
+			if (beta != 0.0)
+#pragma unroll
+				for (int i = 0; i < TM; ++i)
+#pragma unroll
+					for (int j = 0; j < TN; ++j)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) cold[i][j][r] = C[c_index(i, j, r)];
+
+			d4 acc[TM][TN];
+#pragma unroll
+			for (int i = 0; i < TM; ++i)
+#pragma unroll
+				for (int j = 0; j < TN; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+			for (int it0 = 0; it0 < nk; it0 += DEPTH)
+			{
+#pragma unroll
+				for (int p = 0; p < DEPTH; ++p)
+				{
+					const int it = it0 + p;
+					if (it < nk) // uniform
+					{
+						// ring slot p was last read in step it - DEPTH; every wave has passed DEPTH - 1 barriers since
+						la[p].store(As + p * BK * AS, t);
+						lb[p].store(Bs + p * BK * BS, t);
+						if (it + DEPTH < nk)
+						{
+							la[p].load(a_at(kb + (it + DEPTH) * BK), g.lda, t);
+							lb[p].load(b_at(kb + (it + DEPTH) * BK), g.ldb, t);
+						}
+						__syncthreads();
+						const double* __restrict__ a = As + p * BK * AS + wm * WTM + fr;
+						const double* __restrict__ b = Bs + p * BK * BS + wn * WTN + fr;
+#pragma unroll
+						for (int kk = 0; kk < BK; kk += 4)
+						{
+							double af[TM], bf[TN];
+#pragma unroll
+							for (int i = 0; i < TM; ++i) af[i] = a[(kk + fk) * AS + i * 16];
+#pragma unroll
+							for (int j = 0; j < TN; ++j) bf[j] = b[(kk + fk) * BS + j * 16];
+#pragma unroll
+							for (int i = 0; i < TM; ++i)
+#pragma unroll
+								for (int j = 0; j < TN; ++j)
+								{
+									if constexpr (CT) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+									else acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+								}
+						}
+					}
+				}
+			}
+
+#pragma unroll
+			for (int i = 0; i < TM; ++i)
+#pragma unroll
+				for (int j = 0; j < TN; ++j)
+#pragma unroll
+					for (int r = 0; r < 4; ++r)
+					{
+						double val = alpha * acc[i][j][r];
+						if (beta != 0.0) val += beta * cold[i][j][r];
+						C[c_index(i, j, r)] = val;
+					}
+		}
+
 		template <int T>
 		hipError_t launch_tile(hipStream_t s, const GemmDesc& d)
 		{
@@ -193,7 +315,8 @@ namespace gple
 #define GPLE_GEMM_CASE(ak, bk, ct)                                                           \
 	if (d.a_kmajor == ak && d.b_kmajor == bk && d.c_trans == ct)                              \
 	{                                                                                         \
-		hipLaunchKernelGGL((gemm_f64_kernel<T, T, ak, bk, ct>), grid, block, 0, s, d);        \
+		if constexpr (T == 64) hipLaunchKernelGGL((gemm_f64_deep_kernel<ak, bk, ct>), grid, block, 0, s, d); \
+		else hipLaunchKernelGGL((gemm_f64_kernel<T, T, ak, bk, ct>), grid, block, 0, s, d);    \
 		return hipGetLastError();                                                             \
 	}
 			GPLE_GEMM_CASE(false, false, false)
