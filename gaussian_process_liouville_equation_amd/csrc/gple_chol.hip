@@ -80,14 +80,44 @@ namespace gple
 				if (j + 1 > K) a[j + 1] = fma(-l, q.c[i].y, a[j + 1]);
 			}
 		}
-		template <int K>
-		__device__ __forceinline__ void rank1_update(double (&a)[NB], unsigned addr, double l)
+		template <int N>
+		__device__ __forceinline__ void lds_wait_scalar(double& r)
 		{
+			asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N));
+		}
+
+		// One column of the panel sweep.  All waves run the same instruction stream (no branches: control flow between
+		// the unrolled columns makes hipcc spill kilobytes per lane); stores only wave 0 should make go to a dump slot.
+		template <int K>
+		__device__ __forceinline__ void panel_column(double (&a)[NB], double (*col)[NB + 2], double* dump, int lane, bool diag, int& first_bad)
+		{
+			double* const cb = &col[K & 1][0];
+			double* const my_col = diag ? &cb[lane] : &dump[threadIdx.x];
+			double* const my_r = (diag && lane == 0) ? &cb[NB] : &dump[threadIdx.x];
+			const double d = readlane_f64(a[K], K); // the pivot in wave 0; a harmless number in the other waves
+			first_bad = (first_bad == 0 && !(d > 0.0)) ? K + 1 : first_bad;
+			const double r0 = rsqrt_newton(d); // NaN for d <= 0: propagates, like the sqrt of a negative pivot
+			double sd = d * r0;
+			sd = fma(fma(-sd, sd, d), 0.5 * r0, sd); // sqrt(d) with a correction step
+			*my_col = lane == K ? sd : (lane > K ? a[K] * r0 : 0.0);
+			*my_r = r0;
+			__syncthreads(); // the only barrier of the column: col[] is double-buffered
+
+			// 1/L_kk and the first chunk of the column are requested together (one LDS round trip, not two); from then on
+			// two chunks are in flight while the previous one is applied
+			const unsigned addr = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) double*)cb));
 			constexpr int CF = (K + 1) / 16; // first chunk holding an entry > K
-			if constexpr (K + 1 < NB)
+			constexpr bool ANY = K + 1 < NB;
+			double r;
+			asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(NB * 8));
+			Chunk q0, q1;
+			if constexpr (ANY) lds_read8<CF * 128>(q0, addr);
+			lds_wait_scalar<ANY ? 8 : 0>(r);
+			const double lp = a[K] * r;
+			const double l = diag ? (lane == K ? sd : (lane > K ? lp : 0.0)) : lp;
+			a[K] = l;
+			if constexpr (ANY)
 			{
-				Chunk q0, q1;
-				lds_read8<CF * 128>(q0, addr);
 				if constexpr (CF + 1 < 4) lds_read8<(CF + 1) * 128>(q1, addr);
 				lds_wait<(CF + 1 < 4) ? 8 : 0>(q0);
 				apply_chunk<K, CF>(a, q0, l);
@@ -109,29 +139,6 @@ namespace gple
 					apply_chunk<K, CF + 3>(a, q1, l);
 				}
 			}
-		}
-
-		// One column of the panel sweep.  All waves run the same instruction stream (no branches: control flow between
-		// the unrolled columns makes hipcc spill kilobytes per lane); stores only wave 0 should make go to a dump slot.
-		template <int K>
-		__device__ __forceinline__ void panel_column(double (&a)[NB], double (*col)[NB + 2], double* dump, int lane, bool diag, int& first_bad)
-		{
-			double* const cb = &col[K & 1][0];
-			double* const my_col = diag ? &cb[lane] : &dump[threadIdx.x];
-			double* const my_r = (diag && lane == 0) ? &cb[NB] : &dump[threadIdx.x];
-			const double d = readlane_f64(a[K], K); // the pivot in wave 0; a harmless number in the other waves
-			first_bad = (first_bad == 0 && !(d > 0.0)) ? K + 1 : first_bad;
-			const double r0 = rsqrt_newton(d); // NaN for d <= 0: propagates, like the sqrt of a negative pivot
-			double sd = d * r0;
-			sd = fma(fma(-sd, sd, d), 0.5 * r0, sd); // sqrt(d) with a correction step
-			*my_col = lane == K ? sd : (lane > K ? a[K] * r0 : 0.0);
-			*my_r = r0;
-			__syncthreads(); // the only barrier of the column: col[] is double-buffered
-			const double r = cb[NB];
-			const double lp = a[K] * r;
-			const double l = diag ? (lane == K ? sd : (lane > K ? lp : 0.0)) : lp;
-			a[K] = l;
-			rank1_update<K>(a, static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) double*)cb)), l);
 		}
 		template <int... Ks>
 		__device__ __forceinline__ void panel_columns(double (&a)[NB], double (*col)[NB + 2], double* dump, int lane, bool diag, int& first_bad,
