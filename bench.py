@@ -107,9 +107,9 @@ def main():
     def step():
         h = C.c_void_p()
         if cplx:
-            st = api.lib.gple_complex_fit_create(api.ctx, thp, dp(dX), dp(dy), N, flags, C.byref(sc), C.byref(h))
+            st = api.lib.gple_complex_fit_create(api.ctx, thp, dp(dX), dp(dy), N, flags, None, C.byref(h))
         else:
-            st = api.lib.gple_real_fit_create(api.ctx, thp, dp(dX), dp(dy), 0, N, flags, C.byref(sc), C.byref(h))
+            st = api.lib.gple_real_fit_create(api.ctx, thp, dp(dX), dp(dy), 0, N, flags, None, C.byref(h))
         if st != 0:
             raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
         fn = api.lib.gple_complex_predict if cplx else api.lib.gple_real_predict
@@ -123,6 +123,11 @@ def main():
                 host = torch.empty(out_full.shape, dtype=out_full.dtype)
                 dist.all_gather_into_tensor(host, out_local.cpu())
                 out_full.copy_(host)
+        # the fit's scalar members (error, population, <r>, purity): the one host synchronisation of the step; fit and
+        # predict above only enqueue
+        st = (api.lib.gple_complex_fit_get_scalars if cplx else api.lib.gple_real_fit_get_scalars)(h, C.byref(sc))
+        if st != 0 or not np.isfinite(sc.purity):
+            raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode() or "non-finite fit scalars")
         (api.lib.gple_complex_fit_release if cplx else api.lib.gple_real_fit_release)(h)
 
     for _ in range(args.warmup):

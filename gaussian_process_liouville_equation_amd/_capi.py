@@ -90,8 +90,8 @@ def _cplx(y):
 GPLE_SYMBOLS = [
     "ctx_create", "ctx_destroy", "ctx_synchronize", "status_string", "ctx_last_error", "ctx_enable_timing", "ctx_get_timing",
     "real_gram", "cutoff_factor",
-    "real_fit_create", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
-    "complex_fit_create", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
+    "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
+    "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
     "complex_predict", "loose_function", "nlml", "nlml_predict",
 ]
 
@@ -99,10 +99,18 @@ GPLE_SYMBOLS = [
 class _Fit:
     """Owns one fit handle of either backend (RAII, like the reference's value-semantic kernel objects)."""
 
-    def __init__(self, api, handle, kind, N, scalars):
+    def __init__(self, api, handle, kind, N, scalars=None):
         self.api, self.handle, self.kind, self.N = api, handle, kind, N
-        self.scalars = scalars
+        self._scalars = scalars  # None: deferred create, fetched (with a stream sync) when a getter first needs them
         api._fits.add(self)
+
+    @property
+    def scalars(self):
+        if self._scalars is None:
+            sc = RealFitScalars() if self.kind == "real" else ComplexFitScalars()
+            self.api._check(self.api._fn(f"{self.kind}_fit_get_scalars")(self.handle, C.byref(sc)))
+            self._scalars = scalars_to_dict(sc)
+        return self._scalars
 
     def release(self):
         if self.handle:
@@ -172,6 +180,9 @@ class Api:
             f = self._fn(name)
             f.argtypes, f.restype = argtypes, C.c_int
         if self.with_ctx:
+            for kind, st in (("real", RealFitScalars), ("complex", ComplexFitScalars)):
+                f = self._fn(f"{kind}_fit_get_scalars")
+                f.argtypes, f.restype = [vp, C.POINTER(st)], C.c_int
             self.lib.gple_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
             self.lib.gple_ctx_destroy.argtypes = [C.c_void_p]
             self.lib.gple_ctx_synchronize.argtypes = [C.c_void_p]
@@ -241,14 +252,15 @@ class Api:
         return out
 
     # ---- TrainingKernel / PredictiveKernel -------------------------------------------------------------------
-    def real_fit(self, theta, X, y, flags):
+    def real_fit(self, theta, X, y, flags, defer_scalars=False):
+        defer_scalars = defer_scalars and self.with_ctx  # the oracle computes everything at once
         theta, X = _f64(theta), _points(X)
         is_c = np.iscomplexobj(y)
         yy = _cplx(y).view(np.float64) if is_c else _f64(y)
         sc, h = RealFitScalars(), C.c_void_p()
         self._check(self._fn("real_fit_create")(*self._c(), _ptr(theta), _ptr(X), _ptr(yy), int(is_c), len(X), flags,
-                                                C.byref(sc), C.byref(h)))
-        return _Fit(self, h, "real", len(X), scalars_to_dict(sc))
+                                                None if defer_scalars else C.byref(sc), C.byref(h)))
+        return _Fit(self, h, "real", len(X), None if defer_scalars else scalars_to_dict(sc))
 
     def real_predict(self, fit, Xs, flags=0, labels=None, want=("prediction", "variance", "cutoff")):
         Xs = _points(Xs)
@@ -266,12 +278,13 @@ class Api:
         return d
 
     # ---- TrainingComplexKernel / PredictiveComplexKernel ------------------------------------------------------
-    def complex_fit(self, theta, X, y, flags):
+    def complex_fit(self, theta, X, y, flags, defer_scalars=False):
+        defer_scalars = defer_scalars and self.with_ctx
         theta, X, yy = _f64(theta), _points(X), _cplx(y).view(np.float64)
         sc, h = ComplexFitScalars(), C.c_void_p()
-        self._check(self._fn("complex_fit_create")(*self._c(), _ptr(theta), _ptr(X), _ptr(yy), len(X), flags, C.byref(sc),
-                                                   C.byref(h)))
-        return _Fit(self, h, "complex", len(X), scalars_to_dict(sc))
+        self._check(self._fn("complex_fit_create")(*self._c(), _ptr(theta), _ptr(X), _ptr(yy), len(X), flags,
+                                                   None if defer_scalars else C.byref(sc), C.byref(h)))
+        return _Fit(self, h, "complex", len(X), None if defer_scalars else scalars_to_dict(sc))
 
     def complex_predict(self, fit, Xs, flags=0, labels=None, want=("prediction", "variance", "cutoff")):
         Xs = _points(Xs)

@@ -30,64 +30,54 @@ namespace gple
 		(void)hipGetLastError();
 		return e == hipErrorOutOfMemory ? GPLE_ERR_ALLOC : GPLE_ERR_HIP;
 	}
+	static bool take_event(Ctx* c, hipEvent_t* e)
+	{
+		if (!c->ev_free.empty())
+		{
+			*e = c->ev_free.back();
+			c->ev_free.pop_back();
+			return true;
+		}
+		return hipEventCreate(e) == hipSuccess;
+	}
 	void timer_start(Ctx* c, int which)
 	{
-		if (c->timing) (void)hipEventRecord(c->ev[2 * which], c->stream);
+		if (!c->timing || c->pending.size() >= 8192) return; // nobody collects: stop recording rather than grow
+		Ctx::TimedSpan sp{which, nullptr, nullptr};
+		if (!take_event(c, &sp.e0)) return;
+		if (!take_event(c, &sp.e1))
+		{
+			c->ev_free.push_back(sp.e0);
+			return;
+		}
+		(void)hipEventRecord(sp.e0, c->stream);
+		c->open_span[which] = sp;
 	}
 	void timer_stop(Ctx* c, int which)
 	{
-		if (c->timing)
-		{
-			(void)hipEventRecord(c->ev[2 * which + 1], c->stream);
-			c->ev_pending[which] = true;
-		}
+		Ctx::TimedSpan& sp = c->open_span[which];
+		if (!sp.e0) return;
+		(void)hipEventRecord(sp.e1, c->stream);
+		c->pending.push_back(sp);
+		sp = Ctx::TimedSpan{};
 	}
-	void chunk_timer_start(Ctx* c)
-	{
-		if (!c->timing) return;
-		if (static_cast<size_t>(2 * c->chunk_ev_used + 1) >= c->chunk_ev.size())
-		{
-			hipEvent_t e0 = nullptr, e1 = nullptr;
-			if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
-			c->chunk_ev.push_back(e0);
-			c->chunk_ev.push_back(e1);
-		}
-		(void)hipEventRecord(c->chunk_ev[2 * c->chunk_ev_used], c->stream);
-	}
-	void chunk_timer_stop(Ctx* c)
-	{
-		if (!c->timing || static_cast<size_t>(2 * c->chunk_ev_used + 1) >= c->chunk_ev.size()) return;
-		(void)hipEventRecord(c->chunk_ev[2 * c->chunk_ev_used + 1], c->stream);
-		c->chunk_ev_used += 1;
-	}
+	void chunk_timer_start(Ctx* c) { timer_start(c, GPLE_TIMER_PREDICT_KERNEL); }
+	void chunk_timer_stop(Ctx* c) { timer_stop(c, GPLE_TIMER_PREDICT_KERNEL); }
 	void timer_collect(Ctx* c)
 	{
-		if (!c->timing) return;
-		if (c->chunk_ev_used > 0)
+		for (const Ctx::TimedSpan& sp : c->pending)
 		{
-			double sum = 0.0;
-			for (int i = 0; i < c->chunk_ev_used; ++i)
+			float ms = 0.f;
+			if (hipEventElapsedTime(&ms, sp.e0, sp.e1) == hipSuccess)
 			{
-				float ms = 0.f;
-				if (hipEventElapsedTime(&ms, c->chunk_ev[2 * i], c->chunk_ev[2 * i + 1]) == hipSuccess) sum += ms;
+				c->t_last[sp.which] = ms;
+				c->t_total[sp.which] += ms;
+				c->t_count[sp.which] += 1;
 			}
-			c->t_last[GPLE_TIMER_PREDICT_KERNEL] = sum;
-			c->t_total[GPLE_TIMER_PREDICT_KERNEL] += sum;
-			c->t_count[GPLE_TIMER_PREDICT_KERNEL] += c->chunk_ev_used; // per rownorm_kernel launch
-			c->chunk_ev_used = 0;
+			c->ev_free.push_back(sp.e0);
+			c->ev_free.push_back(sp.e1);
 		}
-		for (int w = 0; w < 3; ++w)
-			if (c->ev_pending[w])
-			{
-				float ms = 0.f;
-				if (hipEventElapsedTime(&ms, c->ev[2 * w], c->ev[2 * w + 1]) == hipSuccess)
-				{
-					c->t_last[w] = ms;
-					c->t_total[w] += ms;
-					c->t_count[w] += 1;
-				}
-				c->ev_pending[w] = false;
-			}
+		c->pending.clear();
 	}
 } // namespace gple
 
@@ -200,6 +190,7 @@ struct FitCommon
 	DSpecSet dspec[6];      // complex kernel: derivative blocks of the parameters 1..6 (zero-initialised = inactive)
 	double* sdev = nullptr; // [0] rescale factor, [1..] raw sums, [31] info (as int)
 	double s_host = 0.0;
+	bool sc_ready = false; // host scalars computed (deferred when the caller passed no scalars struct)
 	SEParamSet ps{};
 	double self = 0.0; // k(x*, x*)
 	FitCommon() { std::memset(dspec, 0, sizeof(dspec)); }
@@ -648,9 +639,8 @@ extern "C"
 		(void)hipStreamSynchronize(ctx->stream);
 		for (auto& e : ctx->pool) (void)hipFree(e.p);
 		if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
-		for (hipEvent_t e : ctx->ev)
-			if (e) (void)hipEventDestroy(e);
-		for (hipEvent_t e : ctx->chunk_ev) (void)hipEventDestroy(e);
+		timer_collect(ctx);
+		for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
 		if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
 		delete ctx;
 		return GPLE_OK;
@@ -658,7 +648,9 @@ extern "C"
 	int gple_ctx_synchronize(gple_ctx* ctx)
 	{
 		if (!ctx) return GPLE_ERR_BAD_ARG;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		timer_collect(ctx);
 		return GPLE_OK;
 	}
 	const char* gple_ctx_last_error(const gple_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
@@ -668,17 +660,19 @@ extern "C"
 		if (!ctx) return GPLE_ERR_BAD_ARG;
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
-		if (on && !ctx->ev[0])
-			for (hipEvent_t& e : ctx->ev) GPLE_HIP(ctx, hipEventCreate(&e));
+		GPLE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		timer_collect(ctx); // intervals still in flight belong to the old accumulators
 		ctx->timing = on != 0;
-		for (int w = 0; w < 3; ++w) ctx->t_last[w] = ctx->t_total[w] = 0.0, ctx->t_count[w] = 0, ctx->ev_pending[w] = false;
-		ctx->chunk_ev_used = 0;
+		for (int w = 0; w < 3; ++w) ctx->t_last[w] = ctx->t_total[w] = 0.0, ctx->t_count[w] = 0;
 		return GPLE_OK;
 	}
 	int gple_ctx_get_timing(gple_ctx* ctx, gple_timer which, double* last_ms, double* total_ms, long* count)
 	{
 		if (!ctx || which < 0 || which > 2) return GPLE_ERR_BAD_ARG;
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		GPLE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		timer_collect(ctx);
 		if (last_ms) *last_ms = ctx->t_last[which];
 		if (total_ms) *total_ms = ctx->t_total[which];
 		if (count) *count = ctx->t_count[which];
@@ -742,49 +736,18 @@ extern "C"
 	}
 
 	// ---- TrainingKernel ----------------------------------------------------------------------------------------
-	int gple_real_fit_create(gple_ctx* ctx, const double theta[4], const double* X, const double* y, int y_is_complex, size_t N,
-		unsigned flags, gple_real_fit_scalars* scalars, gple_real_fit** out)
+	// Host side of TrainingKernel's scalar members: drains the stream, reads the raw device sums back and applies the
+	// closed-form factors.  Called with ctx->call_mu held, either from gple_real_fit_create (scalars requested) or later
+	// from gple_real_fit_get_scalars.
+	static int real_fit_finalize(gple_ctx* ctx, gple_real_fit* f)
 	{
-		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 20)) return GPLE_ERR_BAD_ARG;
-		*out = nullptr;
-		std::lock_guard<std::mutex> lk(ctx->call_mu);
-		GPLE_HIP(ctx, hipSetDevice(ctx->device));
-		gple_real_fit* f = new (std::nothrow) gple_real_fit;
-		if (!f) return GPLE_ERR_ALLOC;
-		std::memcpy(f->theta, theta, sizeof(f->theta));
-		const double sf = theta[0], l0 = theta[1], l1 = theta[2], sn = theta[3];
-		f->ps.p[0] = f->ps.p[1] = f->ps.p[2] = make_se(sf * sf, sn * sn, l0, l1);
-		f->self = (sf * sf) * (1.0 + (sn * sn) * 1.0); // KernelBase(params, col, col).get_kernel().value(), kernel.cpp:512
-		f->sf = sf;
 		hipStream_t st = ctx->stream;
-		int status = fit_common(ctx, f, X, y, y_is_complex ? 2 : 1, N, flags);
-		if (status == GPLE_OK)
-		{
-			hipError_t e = launch_real_fit_sums(st, f->Xt, f->ys, f->v, f->w, f->N, f->sdev + 1);
-			if (e == hipSuccess && (flags & GPLE_CALC_AVERAGE))
-			{
-				Scratch part(ctx);
-				const size_t g = (N + 63) / 64;
-				e = part.get(g * g);
-				if (e == hipSuccess) e = launch_quadform(st, f->Xt, f->N, purity_aux(sf, l0, l1), f->v, f->v, -1, part.p, f->sdev + 6);
-			}
-			if (e == hipSuccess && (flags & GPLE_CALC_DERIVATIVE))
-			{
-				status = real_fit_derivatives(ctx, f, sf, l0, l1, sn, flags);
-				if (status != GPLE_OK) e = hipErrorUnknown;
-			}
-			if (e == hipSuccess) e = hipMemcpyAsync(ctx->host_scalars, f->sdev, SDEV_N * 8, hipMemcpyDeviceToHost, st);
-			timer_stop(ctx, GPLE_TIMER_FIT);
-			if (e == hipSuccess) e = hipStreamSynchronize(st);
-			timer_collect(ctx);
-			if (e != hipSuccess && status == GPLE_OK) status = record_hip_error(ctx, e, "real fit reductions", __LINE__);
-		}
-		if (status != GPLE_OK)
-		{
-			(void)hipStreamSynchronize(st);
-			delete f;
-			return status;
-		}
+		GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars, f->sdev, SDEV_N * 8, hipMemcpyDeviceToHost, st));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		timer_collect(ctx);
+		const unsigned flags = f->flags;
+		const size_t N = f->N;
+		const double sf = f->theta[0], l0 = f->theta[1], l1 = f->theta[2];
 		const double* h = ctx->host_scalars;
 		gple_real_fit_scalars& sc = f->sc;
 		fill_nan_scalars(&sc);
@@ -831,8 +794,71 @@ extern "C"
 				for (double& d : sc.purity_derivative) d /= s * s;
 			}
 		}
-		if (scalars) *scalars = sc;
+		f->sc_ready = true;
+		return GPLE_OK;
+	}
+
+	int gple_real_fit_create(gple_ctx* ctx, const double theta[4], const double* X, const double* y, int y_is_complex, size_t N,
+		unsigned flags, gple_real_fit_scalars* scalars, gple_real_fit** out)
+	{
+		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 20)) return GPLE_ERR_BAD_ARG;
+		*out = nullptr;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		gple_real_fit* f = new (std::nothrow) gple_real_fit;
+		if (!f) return GPLE_ERR_ALLOC;
+		std::memcpy(f->theta, theta, sizeof(f->theta));
+		const double sf = theta[0], l0 = theta[1], l1 = theta[2], sn = theta[3];
+		f->ps.p[0] = f->ps.p[1] = f->ps.p[2] = make_se(sf * sf, sn * sn, l0, l1);
+		f->self = (sf * sf) * (1.0 + (sn * sn) * 1.0); // KernelBase(params, col, col).get_kernel().value(), kernel.cpp:512
+		f->sf = sf;
+		hipStream_t st = ctx->stream;
+		int status = fit_common(ctx, f, X, y, y_is_complex ? 2 : 1, N, flags);
+		if (status == GPLE_OK)
+		{
+			hipError_t e = launch_real_fit_sums(st, f->Xt, f->ys, f->v, f->w, f->N, f->sdev + 1);
+			if (e == hipSuccess && (flags & GPLE_CALC_AVERAGE))
+			{
+				Scratch part(ctx);
+				const size_t g = (N + 63) / 64;
+				e = part.get(g * g);
+				if (e == hipSuccess) e = launch_quadform(st, f->Xt, f->N, purity_aux(sf, l0, l1), f->v, f->v, -1, part.p, f->sdev + 6);
+			}
+			if (e == hipSuccess && (flags & GPLE_CALC_DERIVATIVE))
+			{
+				status = real_fit_derivatives(ctx, f, sf, l0, l1, sn, flags);
+				if (status != GPLE_OK) e = hipErrorUnknown;
+			}
+			timer_stop(ctx, GPLE_TIMER_FIT);
+			if (e != hipSuccess && status == GPLE_OK) status = record_hip_error(ctx, e, "real fit reductions", __LINE__);
+		}
+		if (status != GPLE_OK)
+		{
+			(void)hipStreamSynchronize(st);
+			delete f;
+			return status;
+		}
+		if (scalars) // no struct to fill: everything stays enqueued, gple_real_fit_get_scalars() drains the stream later
+		{
+			status = real_fit_finalize(ctx, f);
+			if (status != GPLE_OK)
+			{
+				delete f;
+				return status;
+			}
+			*scalars = f->sc;
+		}
 		*out = f;
+		return GPLE_OK;
+	}
+	int gple_real_fit_get_scalars(gple_real_fit* fit, gple_real_fit_scalars* out)
+	{
+		if (!fit || !out) return GPLE_ERR_BAD_ARG;
+		gple_ctx* ctx = fit->ctx;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		if (!fit->sc_ready) GPLE_TRY(real_fit_finalize(ctx, fit));
+		*out = fit->sc;
 		return GPLE_OK;
 	}
 	int gple_real_fit_retain(gple_real_fit* fit)
@@ -999,7 +1025,7 @@ extern "C"
 		timer_stop(ctx, GPLE_TIMER_PREDICT);
 		// host outputs (and the error scalar) need the stream drained; device-pointer calls without labels stay asynchronous
 		// (pooled scratch is only ever reused by later work on this same stream, which the stream orders)
-		if (!dev || labels || ctx->timing)
+		if (!dev || labels)
 		{
 			GPLE_HIP(ctx, hipStreamSynchronize(st));
 			timer_collect(ctx);
@@ -1017,76 +1043,18 @@ extern "C"
 		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
 	}
 
-	// ---- TrainingComplexKernel ------------------------------------------------------------------------------
-	int gple_complex_fit_create(gple_ctx* ctx, const double theta[8], const double* X, const double* y, size_t N, unsigned flags,
-		gple_complex_fit_scalars* scalars, gple_complex_fit** out)
+	// Host side of TrainingComplexKernel's scalar members (see real_fit_finalize).
+	static int complex_fit_finalize(gple_ctx* ctx, gple_complex_fit* f)
 	{
-		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 19)) return GPLE_ERR_BAD_ARG;
-		*out = nullptr;
-		std::lock_guard<std::mutex> lk(ctx->call_mu);
-		GPLE_HIP(ctx, hipSetDevice(ctx->device));
-		gple_complex_fit* f = new (std::nothrow) gple_complex_fit;
-		if (!f) return GPLE_ERR_ALLOC;
-		f->is_complex = true;
-		std::memcpy(f->theta, theta, sizeof(f->theta));
-		const double s0 = theta[0], sR = theta[1], lR0 = theta[2], lR1 = theta[3], sI = theta[4], lI0 = theta[5], lI1 = theta[6],
-					 sn = theta[7];
-		// correlation kernel parameters, complex_kernel.cpp:144-157
-		const double ss0 = lR0 * lR0 + lI0 * lI0, ss1 = lR1 * lR1 + lI1 * lI1;
-		const double sC = std::sqrt(sR * sI * ((2.0 * lR0 * lI0 / ss0) * (2.0 * lR1 * lI1 / ss1)));
-		const double lC0 = std::sqrt(ss0 / 2.0), lC1 = std::sqrt(ss1 / 2.0);
-		const double m2 = s0 * s0;
-		// blocks of the real covariance of [Re; Im]: Cxx = s^2 (kR + sn^2/2 d), Cyy = s^2 (kI + sn^2/2 d), Cxy = s^2 kC
-		f->ps.p[0] = make_se(m2 * (sR * sR), (sn * sn) / (2.0 * sR * sR), lR0, lR1);
-		f->ps.p[1] = make_se(m2 * (sC * sC), 0.0, lC0, lC1);
-		f->ps.p[2] = make_se(m2 * (sI * sI), (sn * sn) / (2.0 * sI * sI), lI0, lI1);
-		f->self = m2 * (sR * sR * (1.0 + 0.0) + sI * sI * (1.0 + 0.0) + sn * sn * 1.0); // complex_kernel.cpp:632
-		f->s0 = s0;
-		build_dspecs(theta, f->dspec);
 		hipStream_t st = ctx->stream;
-		int status = fit_common(ctx, f, X, y, 2, N, flags);
-		double purity_sums[6] = {0, 0, 0, 0, 0, 0};
-		if (status == GPLE_OK)
-		{
-			hipLaunchKernelGGL(complex_fit_sums_kernel, dim3(1), dim3(1024), 0, st, f->ys, f->v, f->w, f->wx, f->N, f->Np, f->sdev + 1);
-			hipError_t e = hipGetLastError();
-			if (e == hipSuccess && (flags & GPLE_CALC_AVERAGE))
-			{
-				// purity quadratic forms in the [Re; Im] weights w = 2 v (complex_kernel.cpp:287-377):
-				// Re(v^H K1 v) + Re(v^T K2 v) = 2 vr'KR'vr + 2 vi'KI'vi + 2 (vr'KC'vr + vi'KC'vi) + 4 vr'(KRC + KIC)vi
-				Scratch part(ctx);
-				const size_t g = (N + 63) / 64;
-				e = part.get(g * g);
-				const SEParam aR = purity_aux(sR, lR0, lR1), aI = purity_aux(sI, lI0, lI1), aC = purity_aux(sC, lC0, lC1);
-				auto mixed = [](double m1, double a0, double a1, double mb, double b0, double b1) { // complex_kernel.cpp:206-219
-					const double prod = (0.5 * (1.0 / (a0 * a0) + 1.0 / (b0 * b0))) * (0.5 * (1.0 / (a1 * a1) + 1.0 / (b1 * b1)));
-					const double m = m1 * mb / std::sqrt(std::sqrt(prod));
-					return make_se(m * m, 0.0, std::sqrt(a0 * a0 + b0 * b0), std::sqrt(a1 * a1 + b1 * b1));
-				};
-				const SEParam aRC = mixed(sR, lR0, lR1, sC, lC0, lC1), aIC = mixed(sI, lI0, lI1, sC, lC0, lC1);
-				const double *wr = f->v, *wi = f->v + f->Np;
-				const SEParam ks[6] = {aR, aI, aC, aC, aRC, aIC};
-				const double* as[6] = {wr, wi, wr, wi, wr, wr};
-				const double* bs[6] = {wr, wi, wr, wi, wi, wi};
-				for (int q = 0; q < 6 && e == hipSuccess; ++q) e = launch_quadform(st, f->Xt, f->N, ks[q], as[q], bs[q], -1, part.p, f->sdev + 8 + q);
-			}
-			if (e == hipSuccess && (flags & GPLE_CALC_DERIVATIVE))
-			{
-				status = complex_fit_derivatives(ctx, f, theta, flags);
-				if (status != GPLE_OK) e = hipErrorUnknown;
-			}
-			if (e == hipSuccess) e = hipMemcpyAsync(ctx->host_scalars, f->sdev, SDEV_N * 8, hipMemcpyDeviceToHost, st);
-			timer_stop(ctx, GPLE_TIMER_FIT);
-			if (e == hipSuccess) e = hipStreamSynchronize(st);
-			timer_collect(ctx);
-			if (e != hipSuccess && status == GPLE_OK) status = record_hip_error(ctx, e, "complex fit reductions", __LINE__);
-		}
-		if (status != GPLE_OK)
-		{
-			(void)hipStreamSynchronize(st);
-			delete f;
-			return status;
-		}
+		GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars, f->sdev, SDEV_N * 8, hipMemcpyDeviceToHost, st));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		timer_collect(ctx);
+		const unsigned flags = f->flags;
+		const size_t N = f->N;
+		const double* theta = f->theta;
+		const double s0 = theta[0];
+		double purity_sums[6];
 		const double* h = ctx->host_scalars;
 		for (int q = 0; q < 6; ++q) purity_sums[q] = h[8 + q];
 		gple_complex_fit_scalars& sc = f->sc;
@@ -1117,8 +1085,97 @@ extern "C"
 				for (int ip = 0; ip < 8; ++ip) sc.error_derivative[ip] = h[32 + ip];
 			if (flags & GPLE_CALC_AVERAGE) complex_purity_derivative(theta, h, s, sc.purity_derivative);
 		}
-		if (scalars) *scalars = sc;
+		f->sc_ready = true;
+		return GPLE_OK;
+	}
+
+	// ---- TrainingComplexKernel ------------------------------------------------------------------------------
+	int gple_complex_fit_create(gple_ctx* ctx, const double theta[8], const double* X, const double* y, size_t N, unsigned flags,
+		gple_complex_fit_scalars* scalars, gple_complex_fit** out)
+	{
+		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 19)) return GPLE_ERR_BAD_ARG;
+		*out = nullptr;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		gple_complex_fit* f = new (std::nothrow) gple_complex_fit;
+		if (!f) return GPLE_ERR_ALLOC;
+		f->is_complex = true;
+		std::memcpy(f->theta, theta, sizeof(f->theta));
+		const double s0 = theta[0], sR = theta[1], lR0 = theta[2], lR1 = theta[3], sI = theta[4], lI0 = theta[5], lI1 = theta[6],
+					 sn = theta[7];
+		// correlation kernel parameters, complex_kernel.cpp:144-157
+		const double ss0 = lR0 * lR0 + lI0 * lI0, ss1 = lR1 * lR1 + lI1 * lI1;
+		const double sC = std::sqrt(sR * sI * ((2.0 * lR0 * lI0 / ss0) * (2.0 * lR1 * lI1 / ss1)));
+		const double lC0 = std::sqrt(ss0 / 2.0), lC1 = std::sqrt(ss1 / 2.0);
+		const double m2 = s0 * s0;
+		// blocks of the real covariance of [Re; Im]: Cxx = s^2 (kR + sn^2/2 d), Cyy = s^2 (kI + sn^2/2 d), Cxy = s^2 kC
+		f->ps.p[0] = make_se(m2 * (sR * sR), (sn * sn) / (2.0 * sR * sR), lR0, lR1);
+		f->ps.p[1] = make_se(m2 * (sC * sC), 0.0, lC0, lC1);
+		f->ps.p[2] = make_se(m2 * (sI * sI), (sn * sn) / (2.0 * sI * sI), lI0, lI1);
+		f->self = m2 * (sR * sR * (1.0 + 0.0) + sI * sI * (1.0 + 0.0) + sn * sn * 1.0); // complex_kernel.cpp:632
+		f->s0 = s0;
+		build_dspecs(theta, f->dspec);
+		hipStream_t st = ctx->stream;
+		int status = fit_common(ctx, f, X, y, 2, N, flags);
+		if (status == GPLE_OK)
+		{
+			hipLaunchKernelGGL(complex_fit_sums_kernel, dim3(1), dim3(1024), 0, st, f->ys, f->v, f->w, f->wx, f->N, f->Np, f->sdev + 1);
+			hipError_t e = hipGetLastError();
+			if (e == hipSuccess && (flags & GPLE_CALC_AVERAGE))
+			{
+				// purity quadratic forms in the [Re; Im] weights w = 2 v (complex_kernel.cpp:287-377):
+				// Re(v^H K1 v) + Re(v^T K2 v) = 2 vr'KR'vr + 2 vi'KI'vi + 2 (vr'KC'vr + vi'KC'vi) + 4 vr'(KRC + KIC)vi
+				Scratch part(ctx);
+				const size_t g = (N + 63) / 64;
+				e = part.get(g * g);
+				const SEParam aR = purity_aux(sR, lR0, lR1), aI = purity_aux(sI, lI0, lI1), aC = purity_aux(sC, lC0, lC1);
+				auto mixed = [](double m1, double a0, double a1, double mb, double b0, double b1) { // complex_kernel.cpp:206-219
+					const double prod = (0.5 * (1.0 / (a0 * a0) + 1.0 / (b0 * b0))) * (0.5 * (1.0 / (a1 * a1) + 1.0 / (b1 * b1)));
+					const double m = m1 * mb / std::sqrt(std::sqrt(prod));
+					return make_se(m * m, 0.0, std::sqrt(a0 * a0 + b0 * b0), std::sqrt(a1 * a1 + b1 * b1));
+				};
+				const SEParam aRC = mixed(sR, lR0, lR1, sC, lC0, lC1), aIC = mixed(sI, lI0, lI1, sC, lC0, lC1);
+				const double *wr = f->v, *wi = f->v + f->Np;
+				const SEParam ks[6] = {aR, aI, aC, aC, aRC, aIC};
+				const double* as[6] = {wr, wi, wr, wi, wr, wr};
+				const double* bs[6] = {wr, wi, wr, wi, wi, wi};
+				for (int q = 0; q < 6 && e == hipSuccess; ++q) e = launch_quadform(st, f->Xt, f->N, ks[q], as[q], bs[q], -1, part.p, f->sdev + 8 + q);
+			}
+			if (e == hipSuccess && (flags & GPLE_CALC_DERIVATIVE))
+			{
+				status = complex_fit_derivatives(ctx, f, theta, flags);
+				if (status != GPLE_OK) e = hipErrorUnknown;
+			}
+			timer_stop(ctx, GPLE_TIMER_FIT);
+			if (e != hipSuccess && status == GPLE_OK) status = record_hip_error(ctx, e, "complex fit reductions", __LINE__);
+		}
+		if (status != GPLE_OK)
+		{
+			(void)hipStreamSynchronize(st);
+			delete f;
+			return status;
+		}
+		if (scalars) // no struct to fill: everything stays enqueued, gple_complex_fit_get_scalars() drains the stream later
+		{
+			status = complex_fit_finalize(ctx, f);
+			if (status != GPLE_OK)
+			{
+				delete f;
+				return status;
+			}
+			*scalars = f->sc;
+		}
 		*out = f;
+		return GPLE_OK;
+	}
+	int gple_complex_fit_get_scalars(gple_complex_fit* fit, gple_complex_fit_scalars* out)
+	{
+		if (!fit || !out) return GPLE_ERR_BAD_ARG;
+		gple_ctx* ctx = fit->ctx;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		if (!fit->sc_ready) GPLE_TRY(complex_fit_finalize(ctx, fit));
+		*out = fit->sc;
 		return GPLE_OK;
 	}
 	int gple_complex_fit_retain(gple_complex_fit* fit)

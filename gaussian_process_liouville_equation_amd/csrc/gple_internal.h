@@ -75,19 +75,24 @@ namespace gple
 		std::mutex mu; // guards last_error + scratch (predict calls may come from several host threads)
 		// pinned host block for scalar results
 		double* host_scalars = nullptr;
-		// tracing (gple_ctx_enable_timing): event pairs per gple_timer
+		// tracing (gple_ctx_enable_timing): every timed interval takes an event pair from a free list and joins `pending`
+		// until the next stream synchronisation collects it, so that timing never forces a synchronisation of its own
+		struct TimedSpan
+		{
+			int which;
+			hipEvent_t e0, e1;
+		};
 		bool timing = false;
-		hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-		bool ev_pending[3] = {false, false, false};
+		std::vector<hipEvent_t> ev_free;
+		std::vector<TimedSpan> pending;
+		TimedSpan open_span[4] = {}; // per gple_timer; [3] is unused padding
 		double t_last[3] = {0, 0, 0}, t_total[3] = {0, 0, 0};
 		long t_count[3] = {0, 0, 0};
-		// one event pair per rownorm_kernel launch of the current predict call (GPLE_TIMER_PREDICT_KERNEL)
-		std::vector<hipEvent_t> chunk_ev;
-		int chunk_ev_used = 0;
 	};
+	// one interval per rownorm_kernel launch (GPLE_TIMER_PREDICT_KERNEL)
 	void chunk_timer_start(Ctx* c);
 	void chunk_timer_stop(Ctx* c);
-	// record the start / stop event of timer `which` (no-ops unless timing is on); collect after a stream sync
+	// record the start / stop event of timer `which` (no-ops unless timing is on); timer_collect() after a stream sync
 	void timer_start(Ctx* c, int which);
 	void timer_stop(Ctx* c, int which);
 	void timer_collect(Ctx* c);

@@ -88,7 +88,12 @@ class _TrainingBase:
         self._fit, self._api, self._flags = fit, api, flags
         self.Params = list(map(float, Parameter))
         self.LeftFeature = np.array(TrainingSet[0], dtype=float)
-        self._s = fit.scalars
+
+    @property
+    def _s(self):
+        # the scalar members are fetched when a getter first asks (one stream synchronisation); constructing the kernel
+        # and predicting from it only enqueue device work
+        return self._fit.scalars
 
     def _need(self, flag):
         assert self._flags & flag, "this quantity was not requested at construction"
@@ -134,7 +139,7 @@ class TrainingKernel(_TrainingBase):
         api = api or default_api()
         assert len(Parameter) == self.NumTotalParameters
         flags = _flags(IsToCalculateError, IsToCalculateAverage, IsToCalculateDerivative)
-        fit = api.real_fit(Parameter, TrainingSet[0], TrainingSet[1], flags)
+        fit = api.real_fit(Parameter, TrainingSet[0], TrainingSet[1], flags, defer_scalars=True)
         super().__init__(fit, Parameter, TrainingSet, flags, api)
 
     def get_formatted_parameters(self):
@@ -176,7 +181,7 @@ class TrainingComplexKernel(_TrainingBase):
         api = api or default_api()
         assert len(Parameter) == self.NumTotalParameters
         flags = _flags(IsToCalculateError, IsToCalculateAverage, IsToCalculateDerivative)
-        fit = api.complex_fit(Parameter, TrainingSet[0], TrainingSet[1], flags)
+        fit = api.complex_fit(Parameter, TrainingSet[0], TrainingSet[1], flags, defer_scalars=True)
         super().__init__(fit, Parameter, TrainingSet, flags, api)
 
     def get_kernel(self):

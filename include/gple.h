@@ -135,9 +135,14 @@ int gple_cutoff_factor(gple_ctx* ctx, const double* prediction, int is_complex, 
 
 /* ---- TrainingKernel (kernel.cpp:244-479) ---------------------------------------------------------- */
 /* theta = (sf, lx, lp, sn); X = 2N; y: N labels; y_is_complex != 0 means y holds N (re,im) pairs of which
- * the real part is used (ElementTrainingSet = tuple<PhasePoints, VectorXcd>, kernel.h:14, kernel.cpp:280). */
+ * the real part is used (ElementTrainingSet = tuple<PhasePoints, VectorXcd>, kernel.h:14, kernel.cpp:280).
+ * scalars == NULL defers the scalar members: with device-resident inputs (GPLE_IO_DEVICE) the call then only enqueues
+ * work and returns; gple_real_fit_get_scalars() drains the stream when a getter is first needed. */
 int gple_real_fit_create(gple_ctx* ctx, const double theta[4], const double* X, const double* y, int y_is_complex,
 	size_t N, unsigned flags, gple_real_fit_scalars* scalars, gple_real_fit** out);
+/* The scalar getters of TrainingKernel (kernel.h:181-243: rescale factor, magnitude, error, population, <r>, purity and
+ * their derivatives); synchronises the context's stream on first use after a deferred create. */
+int gple_real_fit_get_scalars(gple_real_fit* fit, gple_real_fit_scalars* scalars);
 int gple_real_fit_retain(gple_real_fit* fit);
 int gple_real_fit_release(gple_real_fit* fit);
 size_t gple_real_fit_size(const gple_real_fit* fit);
@@ -157,6 +162,8 @@ int gple_real_predict(gple_ctx* ctx, const gple_real_fit* fit, const double* Xs,
 /* theta = (s, sR, lRx, lRp, sI, lIx, lIp, sn); y = N (re,im) pairs. */
 int gple_complex_fit_create(gple_ctx* ctx, const double theta[8], const double* X, const double* y, size_t N,
 	unsigned flags, gple_complex_fit_scalars* scalars, gple_complex_fit** out);
+/* complex_kernel.h:214-265; deferred like gple_real_fit_get_scalars when the create call passed scalars == NULL. */
+int gple_complex_fit_get_scalars(gple_complex_fit* fit, gple_complex_fit_scalars* scalars);
 int gple_complex_fit_retain(gple_complex_fit* fit);
 int gple_complex_fit_release(gple_complex_fit* fit);
 size_t gple_complex_fit_size(const gple_complex_fit* fit);

@@ -310,3 +310,25 @@ def test_complex_edge_cases(gpu, oracle):
         assert abs(f1g.scalars[k] - f1o.scalars[k]) <= 1e-12 * abs(f1o.scalars[k])
     p1g, p1o = gpu.complex_predict(f1g, Xs), oracle.complex_predict(f1o, Xs)
     assert np.abs(p1g["cutoff"] - p1o["cutoff"]).max() <= 1e-13 and np.abs(p1g["variance"] - p1o["variance"]).max() <= 1e-13
+
+
+def test_deferred_scalars_match_immediate(gpu):
+    """scalars == NULL at create: nothing synchronises until a getter asks; values equal the immediate path bit for bit,
+    and a predict enqueued before the scalars are fetched sees the same fit."""
+    X, y, Xs = parity.synthetic_real(700, 900, 31)
+    theta = [1.0, 0.7086, 0.7056, 1e-2]
+    now = gpu.real_fit(theta, X, y, 7)
+    later = gpu.real_fit(theta, X, y, 7, defer_scalars=True)
+    assert later._scalars is None
+    p_later = gpu.real_predict(later, Xs)
+    assert later._scalars is None  # the predict did not need them
+    p_now = gpu.real_predict(now, Xs)
+    for k, v in now.scalars.items():
+        assert np.array_equal(np.asarray(v), np.asarray(later.scalars[k]), equal_nan=True), k
+    for k in ("prediction", "variance", "cutoff"):
+        assert np.array_equal(p_now[k], p_later[k])
+    yc = 0.5 * y * np.exp(0.5j * (X[:, 0] + 10.0))
+    thc = [1.0, 1.0, 0.7086, 0.7056, 1.2, 0.8, 0.6, 1e-2]
+    cn, cl = gpu.complex_fit(thc, X[:300], yc[:300], 7), gpu.complex_fit(thc, X[:300], yc[:300], 7, defer_scalars=True)
+    for k, v in cn.scalars.items():
+        assert np.array_equal(np.asarray(v), np.asarray(cl.scalars[k]), equal_nan=True), k
