@@ -26,6 +26,7 @@
 // "Typed" rows/columns implement the complex GP as a real GP on [Re; Im] (see gple_kernels.h, SEParamSet).
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "gple_kernels.h"
 
@@ -145,6 +146,14 @@ namespace gple
 				for (int ip = 0; ip < NACC; ++ip) mu_part[(static_cast<long>(ip + 1) * GEN_KSPLIT + blockIdx.y) * a.m_rows + gm] = dacc[ip];
 		}
 
+		// the k-steps that cross the diagonal 256-block of an N-tile: step D starts at k = n0 + KB D, where the column blocks
+		// j < KB D / 16 are identically zero
+		template <int KB, class Step, int... D>
+		__device__ __forceinline__ void diag_steps(Step& kstep, int nd, std::integer_sequence<int, D...>)
+		{
+			(kstep(std::integral_constant<int, (D * KB) / 16>{}, nd + D), ...);
+		}
+
 		// q[row] = sum_n ( sum_{k <= n} K*(row, k) T(n, k) )^2 for one chunk of rows.
 		// WAVES waves x 16 rows per workgroup, K advances KB per barrier.  <8, 16>: one workgroup fills a CU (2 waves per
 		// SIMD); <4, 8>: two independent workgroups per CU cover each other's barrier / pipeline-fill bubbles (selected with
@@ -228,27 +237,21 @@ namespace gple
 					for (int kk = 0; kk < KB; kk += 4)
 					{
 						const double af = pa[(kk + fk) * ASr];
+						double bf[16];
 #pragma unroll
-						for (int h = JMIN; h < 16; h += 4)
-						{
-							double bf[4];
+						for (int j = JMIN; j < 16; ++j) bf[j] = pb[(kk + fk) * BS + j * 16];
 #pragma unroll
-							for (int j = 0; j < 4; ++j) bf[j] = pb[(kk + fk) * BS + (h + j) * 16];
-#pragma unroll
-							for (int j = 0; j < 4; ++j) acc[h + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af, acc[h + j], 0, 0, 0);
-						}
+						for (int j = JMIN; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af, acc[j], 0, 0, 0);
 					}
 					if (s + 1 < nk) store_ab((s + 1) & 1);
 					__syncthreads();
 				};
-				// k-slabs below the diagonal N-tile and its first 64 columns see every column block; afterwards the column
-				// blocks left of the current k (T(n,k) = 0 for k > n) drop out, 64 columns at a time
-				const int nd = n0 / KB, q64 = 64 / KB;
+				// k-slabs below the diagonal N-tile see every column block; inside the diagonal 256-block the column blocks left
+				// of the current k (T(n,k) = 0 for k > n) drop out one at a time: 16 columns per 16 k
+				const int nd = n0 / KB;
 				int s = 0;
-				for (; s < nd + q64; ++s) kstep(std::integral_constant<int, 0>{}, s);
-				for (; s < nd + 2 * q64; ++s) kstep(std::integral_constant<int, 4>{}, s);
-				for (; s < nd + 3 * q64; ++s) kstep(std::integral_constant<int, 8>{}, s);
-				for (; s < nd + 4 * q64; ++s) kstep(std::integral_constant<int, 12>{}, s);
+				for (; s < nd; ++s) kstep(std::integral_constant<int, 0>{}, s);
+				diag_steps<KB>(kstep, nd, std::make_integer_sequence<int, BN / KB>{});
 
 				// result element [n = 16 j + fk + 4 r][m = 16 w + fr]: the row index m is lane-local
 #pragma unroll
