@@ -275,6 +275,33 @@ namespace gple
 			for (int ky = 0; ky < GEN_KSPLIT; ++ky) s += p[static_cast<long>(ky) * m_rows + i];
 			out[static_cast<long>(blockIdx.y) * m_rows + i] = s;
 		}
+		// q[m] = sum_n Z(n, m)^2 (column m of the n x rows matrix Z = T K*^T): one workgroup per test row
+		__global__ void __launch_bounds__(256) colsumsq_kernel(const double* __restrict__ Z, long ldz, int n, double* __restrict__ q)
+		{
+			__shared__ double red[4];
+			const double* __restrict__ z = Z + static_cast<long>(blockIdx.x) * ldz;
+			double s = 0.0;
+			for (int i = threadIdx.x; i < n; i += 256) s = fma(z[i], z[i], s);
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+			if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+			__syncthreads();
+			if (threadIdx.x == 0) q[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+		}
+
+		// Few test rows (the extra-point sets of the objective, opt.cpp:441-482; single-point lookups): rownorm_kernel
+		// gives every 128 rows to ONE workgroup that walks all of T — N^2/2 k-steps on 1 of 256 CUs, 0.55 ms at N = 1024 no
+		// matter how few rows there are.  Below SMALL_M_WGS row blocks the contraction is spread over (n/64) x (rows/64)
+		// tiles instead: Z = T K*^T by the triangular-K GEMM, then column sums of squares.
+		constexpr int SMALL_M_WGS = 96;
+		constexpr size_t SMALL_M_Z_DOUBLES = size_t(1) << 26; // 512 MiB of Z at most
+		bool small_m(const PredictArgs& a)
+		{
+			const bool fits = static_cast<size_t>(a.m_rows) * a.n_total <= SMALL_M_Z_DOUBLES;
+			const char* force = getenv("GPLE_PREDICT_SMALL_M"); // "0" / "1": A/B runs and the path-against-path parity test
+			if (force && (force[0] == '0' || force[0] == '1')) return force[0] == '1' && fits;
+			return a.m_rows / BM <= SMALL_M_WGS && fits;
+		}
 	} // namespace
 
 	size_t predict_scratch_doubles(const PredictArgs& a, int* chunk_rows)
@@ -284,8 +311,10 @@ namespace gple
 		size_t rows = PREDICT_SCRATCH_BYTES / per_row / BM * BM;
 		if (rows < static_cast<size_t>(BM)) rows = BM;
 		if (rows > static_cast<size_t>(a.m_rows)) rows = a.m_rows;
+		if (small_m(a)) rows = a.m_rows; // one chunk (<= 512 MiB), plus Z of the same size
 		*chunk_rows = static_cast<int>(rows);
-		return rows * a.n_total + static_cast<size_t>(GEN_KSPLIT) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1);
+		return rows * a.n_total + static_cast<size_t>(GEN_KSPLIT) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1)
+			+ (small_m(a) ? rows * a.n_total : 0);
 	}
 
 	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows)
@@ -299,6 +328,8 @@ namespace gple
 		}();
 		double* Ks = scratch;
 		double* mu_part = scratch + static_cast<size_t>(chunk_rows) * a.n_total;
+		const bool small = small_m(a) && chunk_rows == a.m_rows;
+		double* Z = mu_part + static_cast<size_t>(GEN_KSPLIT) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1);
 		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
 		{
 			const int rows = a.m_rows - row0 < chunk_rows ? a.m_rows - row0 : chunk_rows;
@@ -307,7 +338,19 @@ namespace gple
 			else if (a.dv) hipLaunchKernelGGL(kstar_gen_kernel<1>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
 			else hipLaunchKernelGGL(kstar_gen_kernel<0>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
 			chunk_timer_start(ctx);
-			if (variant == 1) hipLaunchKernelGGL((rownorm_kernel<4, 8>), dim3(rows / 64), dim3(256), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
+			if (small)
+			{
+				GemmDesc g{};
+				g.A = a.T, g.lda = a.ldt, g.B = Ks, g.ldb = rows, g.C = Z, g.ldc = a.n_total;
+				g.M = a.n_total, g.N = rows, g.K = a.n_total, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
+				g.krange = K_LE_M; // T(n, k) = 0 for k > n
+				g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
+				const bool big_tiles = static_cast<long>(a.n_total / 128) * (rows / 128) >= 256;
+				const hipError_t e = launch_gemm(s, g, big_tiles ? 128 : 64);
+				if (e != hipSuccess) return e;
+				hipLaunchKernelGGL(colsumsq_kernel, dim3(rows), dim3(256), 0, s, Z, static_cast<long>(a.n_total), a.n_total, a.q + row0);
+			}
+			else if (variant == 1) hipLaunchKernelGGL((rownorm_kernel<4, 8>), dim3(rows / 64), dim3(256), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
 			else hipLaunchKernelGGL((rownorm_kernel<8, 16>), dim3(rows / BM), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
 			chunk_timer_stop(ctx);
 		}

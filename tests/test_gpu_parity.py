@@ -332,3 +332,25 @@ def test_deferred_scalars_match_immediate(gpu):
     cn, cl = gpu.complex_fit(thc, X[:300], yc[:300], 7), gpu.complex_fit(thc, X[:300], yc[:300], 7, defer_scalars=True)
     for k, v in cn.scalars.items():
         assert np.array_equal(np.asarray(v), np.asarray(cl.scalars[k]), equal_nan=True), k
+
+
+def test_small_m_and_streaming_predict_paths_agree(gpu, monkeypatch):
+    """The few-rows path (Z = T K*^T by the triangular GEMM + column norms) against the streaming MFMA contraction on the
+    same fit and points, real and complex, incl. a row count that is not a tile multiple."""
+    X, y, Xs = parity.synthetic_real(900, 1111, 77)
+    theta = [1.0, 0.7086, 0.7056, 1e-2]
+    fit = gpu.real_fit(theta, X, y, 3)
+    out = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("GPLE_PREDICT_SMALL_M", force)
+        out[force] = gpu.real_predict(fit, Xs)
+    assert np.array_equal(out["0"]["prediction"], out["1"]["prediction"])  # the mean does not depend on the path
+    assert np.abs(out["0"]["variance"] - out["1"]["variance"]).max() <= 1e-11 * (theta[0] ** 2)
+    yc = 0.5 * y * np.exp(0.5j * (X[:, 0] + 10.0))
+    thc = [1.0, 1.0, 0.7086, 0.7056, 1.2, 0.8, 0.6, 1e-2]
+    cfit = gpu.complex_fit(thc, X[:400], yc[:400], 3)
+    for force in ("0", "1"):
+        monkeypatch.setenv("GPLE_PREDICT_SMALL_M", force)
+        out[force] = gpu.complex_predict(cfit, Xs[:333])
+    assert np.array_equal(out["0"]["prediction"], out["1"]["prediction"])
+    assert np.abs(out["0"]["variance"] - out["1"]["variance"]).max() <= 1e-11 * 4.0
