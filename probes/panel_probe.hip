@@ -202,6 +202,22 @@ __device__ __forceinline__ void lds_read8(Chunk& q, unsigned addr)
 				 : "=&v"(q.c[0]), "=&v"(q.c[1]), "=&v"(q.c[2]), "=&v"(q.c[3]), "=&v"(q.c[4]), "=&v"(q.c[5]), "=&v"(q.c[6]), "=&v"(q.c[7])
 				 : "v"(addr), "n"(OFF));
 }
+// the same request tied to a value the preceding FMAs produced: without a data dependency the instruction selector hoists
+// the request above those FMAs, the old chunk stays live and the new one lands in fresh registers (spills)
+template <int OFF>
+__device__ __forceinline__ void lds_read8_after(Chunk& q, unsigned addr, double dep)
+{
+	asm volatile("ds_read_b128 %0, %8 offset:%9\n"
+				 "ds_read_b128 %1, %8 offset:%9+16\n"
+				 "ds_read_b128 %2, %8 offset:%9+32\n"
+				 "ds_read_b128 %3, %8 offset:%9+48\n"
+				 "ds_read_b128 %4, %8 offset:%9+64\n"
+				 "ds_read_b128 %5, %8 offset:%9+80\n"
+				 "ds_read_b128 %6, %8 offset:%9+96\n"
+				 "ds_read_b128 %7, %8 offset:%9+112\n"
+				 : "=&v"(q.c[0]), "=&v"(q.c[1]), "=&v"(q.c[2]), "=&v"(q.c[3]), "=&v"(q.c[4]), "=&v"(q.c[5]), "=&v"(q.c[6]), "=&v"(q.c[7])
+				 : "v"(addr), "n"(OFF), "v"(dep));
+}
 template <int N>
 __device__ __forceinline__ void lds_wait(Chunk& q)
 {
@@ -417,6 +433,206 @@ __global__ void __launch_bounds__(NT) panel_v8(double* __restrict__ A, long lda,
 	STAMP(3)
 }
 
+// V9: wave-specialised, one barrier per BLK columns.  Wave 0 (diagonal block) never waits for LDS on its pivot chain: the
+// next pivot's dependency goes through readlane (fast path), the rest of each rank-1 update is applied one column late from
+// its own published column (same-wave LDS write -> read needs no barrier).  The row wave consumes a block of BLK published
+// columns per barrier.  Blocks are double-buffered.
+constexpr int BLK = 4;
+// chunked a[j] -= l * column[j] for j >= KMIN; on entry the first one (two) chunk reads may already be in flight
+template <int KMIN, bool PREISSUED>
+__device__ __forceinline__ void update_from(double (&a)[NB], unsigned addr, double l, Chunk& q0, Chunk& q1)
+{
+	if constexpr (KMIN < NB)
+	{
+		constexpr int CF = KMIN / 16;
+		if constexpr (!PREISSUED)
+		{
+			lds_read8<CF * 128>(q0, addr);
+			if constexpr (CF + 1 < 4) lds_read8<(CF + 1) * 128>(q1, addr);
+		}
+		lds_wait<(CF + 1 < 4) ? 8 : 0>(q0);
+		apply_chunk_from<KMIN, CF>(a, q0, l);
+		if constexpr (CF + 2 < 4) lds_read8_after<(CF + 2) * 128>(q0, addr, a[16 * CF + 15]);
+		if constexpr (CF + 1 < 4)
+		{
+			lds_wait<(CF + 2 < 4) ? 8 : 0>(q1);
+			apply_chunk_from<KMIN, CF + 1>(a, q1, l);
+			if constexpr (CF + 3 < 4) lds_read8_after<(CF + 3) * 128>(q1, addr, a[16 * (CF + 1) + 15]);
+		}
+		if constexpr (CF + 2 < 4)
+		{
+			lds_wait<(CF + 3 < 4) ? 8 : 0>(q0);
+			apply_chunk_from<KMIN, CF + 2>(a, q0, l);
+		}
+		if constexpr (CF + 3 < 4)
+		{
+			lds_wait<0>(q1);
+			apply_chunk_from<KMIN, CF + 3>(a, q1, l);
+		}
+	}
+}
+template <int KMIN>
+__device__ __forceinline__ void issue_first(unsigned addr, Chunk& q0, Chunk& q1)
+{
+	if constexpr (KMIN < NB)
+	{
+		constexpr int CF = KMIN / 16;
+		lds_read8<CF * 128>(q0, addr);
+		if constexpr (CF + 1 < 4) lds_read8<(CF + 1) * 128>(q1, addr);
+	}
+}
+__device__ __forceinline__ unsigned lds_addr(const double* p)
+{
+	return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const double*)p));
+}
+
+// column C in wave 0.  lprev = this lane's entry of column C - 1, whose deferred update (entries >= C + 1) is applied here;
+// q0/q1 hold its first chunks, requested one column ago.  The pivot chain of column C and the FMAs of that update are
+// independent instruction streams between the two waits, so the scheduler can fill the chain's latency with FMAs.
+template <int C>
+__device__ __forceinline__ void diag_column(double (&a)[NB], double (*colb)[BLK][NB + 2], int lane, double& lprev, Chunk& q0, Chunk& q1)
+{
+	double* const cb = &colb[(C / BLK) & 1][C % BLK][0];
+	constexpr int KMIN = C + 1;
+	constexpr bool DEF = C >= 1 && KMIN < NB; // a deferred update exists
+	constexpr int CF = KMIN / 16;
+	if constexpr (DEF) lds_wait<(CF + 1 < 4) ? 8 : 0>(q0);
+	const double d = readlane_f64(a[C], C);
+	const double r = rsqrt_newton(d);
+	double sd = d * r;
+	sd = fma(fma(-sd, sd, d), 0.5 * r, sd);
+	const double l = lane > C ? a[C] * r : 0.0;
+	a[C] = lane == C ? sd : l;
+	if constexpr (DEF) apply_chunk_from<KMIN, CF>(a, q0, lprev);
+	if constexpr (C + 1 < NB) a[C + 1] = fma(-l, readlane_f64(l, C + 1), a[C + 1]); // fast path: all the next pivot needs
+	if constexpr (DEF)
+	{
+		const unsigned addr = lds_addr(&colb[((C - 1) / BLK) & 1][(C - 1) % BLK][0]);
+		if constexpr (CF + 2 < 4) lds_read8_after<(CF + 2) * 128>(q0, addr, a[16 * CF + 15]);
+		if constexpr (CF + 1 < 4)
+		{
+			lds_wait<(CF + 2 < 4) ? 8 : 0>(q1);
+			apply_chunk_from<KMIN, CF + 1>(a, q1, lprev);
+			if constexpr (CF + 3 < 4) lds_read8_after<(CF + 3) * 128>(q1, addr, a[16 * (CF + 1) + 15]);
+		}
+		if constexpr (CF + 2 < 4)
+		{
+			lds_wait<(CF + 3 < 4) ? 8 : 0>(q0);
+			apply_chunk_from<KMIN, CF + 2>(a, q0, lprev);
+		}
+		if constexpr (CF + 3 < 4)
+		{
+			lds_wait<0>(q1);
+			apply_chunk_from<KMIN, CF + 3>(a, q1, lprev);
+		}
+	}
+	cb[lane] = lane == C ? r : l; // slot C carries 1/L_CC for the row waves; nobody reads L_CC from here
+	if constexpr (C % BLK == BLK - 1 || C == NB - 1) __syncthreads(); // block published
+	if constexpr (C + 2 < NB)
+	{
+		constexpr int CN = (C + 2) / 16;
+		lds_read8_after<CN * 128>(q0, lds_addr(cb), a[NB - 1]); // consumed while the next column's chain runs
+		if constexpr (CN + 1 < 4) lds_read8_after<(CN + 1) * 128>(q1, lds_addr(cb), a[NB - 17]);
+	}
+	lprev = l;
+}
+template <int... Cs>
+__device__ __forceinline__ void diag_columns(double (&a)[NB], double (*colb)[BLK][NB + 2], int lane, std::integer_sequence<int, Cs...>)
+{
+	double lprev = 0.0;
+	Chunk q0, q1;
+	(diag_column<Cs>(a, colb, lane, lprev, q0, q1), ...);
+}
+template <int C>
+__device__ __forceinline__ void row_column(double (&a)[NB], double (*colb)[BLK][NB + 2])
+{
+	if constexpr (C % BLK == 0) __syncthreads(); // the block holding column C has been published
+	const double* const cb = &colb[(C / BLK) & 1][C % BLK][0];
+	const unsigned addr = lds_addr(cb);
+	constexpr int CF = (C + 1) / 16;
+	constexpr bool ANY = C + 1 < NB;
+	double r;
+	// tied to the last entries the previous column updated: keeps that column's FMAs above this column's requests
+	asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(C * 8), "v"(a[NB - 1]), "v"(a[NB - 17]));
+	Chunk q0, q1;
+	if constexpr (ANY) lds_read8<CF * 128>(q0, addr);
+	asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(ANY ? 8 : 0));
+	const double l = a[C] * r;
+	a[C] = l;
+	if constexpr (ANY)
+	{
+		if constexpr (CF + 1 < 4) lds_read8<(CF + 1) * 128>(q1, addr);
+		lds_wait<(CF + 1 < 4) ? 8 : 0>(q0);
+		apply_chunk_from<C + 1, CF>(a, q0, l);
+		if constexpr (CF + 2 < 4) lds_read8_after<(CF + 2) * 128>(q0, addr, a[16 * CF + 15]);
+		if constexpr (CF + 1 < 4)
+		{
+			lds_wait<(CF + 2 < 4) ? 8 : 0>(q1);
+			apply_chunk_from<C + 1, CF + 1>(a, q1, l);
+			if constexpr (CF + 3 < 4) lds_read8_after<(CF + 3) * 128>(q1, addr, a[16 * (CF + 1) + 15]);
+		}
+		if constexpr (CF + 2 < 4)
+		{
+			lds_wait<(CF + 3 < 4) ? 8 : 0>(q0);
+			apply_chunk_from<C + 1, CF + 2>(a, q0, l);
+		}
+		if constexpr (CF + 3 < 4)
+		{
+			lds_wait<0>(q1);
+			apply_chunk_from<C + 1, CF + 3>(a, q1, l);
+		}
+	}
+}
+template <int... Cs>
+__device__ __forceinline__ void row_columns(double (&a)[NB], double (*colb)[BLK][NB + 2], std::integer_sequence<int, Cs...>)
+{
+	(row_column<Cs>(a, colb), ...);
+}
+__device__ __forceinline__ void diag_wave(double* __restrict__ A, long lda, double (*colb)[BLK][NB + 2], int lane, bool store)
+{
+	double a[NB];
+	const double* __restrict__ src = A + lane;
+#pragma unroll
+	for (int j = 0; j < NB; ++j) a[j] = src[static_cast<long>(j) * lda];
+	diag_columns(a, colb, lane, std::make_integer_sequence<int, NB>{});
+	if (store)
+	{
+		int lane2 = lane;
+		asm volatile("" : "+v"(lane2)); // a fresh value: keeps hipcc from holding the 64 load addresses live for the stores
+		double* __restrict__ dst = A + lane2;
+#pragma unroll
+		for (int j = 0; j < NB; ++j) dst[static_cast<long>(j) * lda] = a[j];
+	}
+}
+__device__ __forceinline__ void row_wave(double* __restrict__ A, long lda, double (*colb)[BLK][NB + 2], int row, bool valid)
+{
+	double a[NB];
+	const double* __restrict__ src = A + row;
+#pragma unroll
+	for (int j = 0; j < NB; ++j) a[j] = src[static_cast<long>(j) * lda];
+	row_columns(a, colb, std::make_integer_sequence<int, NB>{});
+	if (valid)
+	{
+		int row2 = row;
+		asm volatile("" : "+v"(row2));
+		double* __restrict__ dst = A + row2;
+#pragma unroll
+		for (int j = 0; j < NB; ++j) dst[static_cast<long>(j) * lda] = a[j];
+	}
+}
+template <bool ST>
+__global__ void __launch_bounds__(128) panel_v9(double* __restrict__ A, long lda, int m, long long* stamps)
+{
+	__shared__ __attribute__((aligned(16))) double colb[2][BLK][NB + 2];
+	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int row = NB + blockIdx.x * 64 + lane;
+	const bool valid = row < m;
+	STAMP(0)
+	if (w == 0) diag_wave(A, lda, colb, lane, blockIdx.x == 0);
+	else row_wave(A, lda, colb, valid ? row : lane, valid);
+	STAMP(2)
+}
+
 // V1: barrier-free, two phases, each in its own non-inlined function so that their 64-entry rows are never live together.
 // MODE 0: phase-1 broadcasts through LDS; MODE 1: through readlane
 template <int MODE>
@@ -496,6 +712,7 @@ __global__ void __launch_bounds__(THREADS) panel_v1(double* __restrict__ A, long
 	STAMP(6)
 }
 
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 int main()
@@ -512,10 +729,10 @@ int main()
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0), hipEventCreate(&e1);
 	std::vector<double> ref;
-	for (int variant = 0; variant < 9; ++variant)
+	for (int variant = 0; variant < 10; ++variant)
 	{
-		const int rows_per_wg = (variant == 5 || variant == 6 || variant == 8) ? 64 : (variant == 0 || variant >= 3) ? 192 : 256;
-		const int nthreads = (variant == 5 || variant == 6 || variant == 8) ? 128 : THREADS;
+		const int rows_per_wg = (variant == 5 || variant == 6 || variant == 8 || variant == 9) ? 64 : (variant == 0 || variant >= 3) ? 192 : 256;
+		const int nthreads = (variant == 5 || variant == 6 || variant == 8 || variant == 9) ? 128 : THREADS;
 		const int nwg = (m - NB + rows_per_wg - 1) / rows_per_wg;
 		auto launch = [&](long long* s) {
 			if (variant == 0 && s) hipLaunchKernelGGL((panel_v0<true>), dim3(nwg), dim3(THREADS), 0, 0, d, lda, m, s);
@@ -529,6 +746,8 @@ int main()
 			if (variant == 7 && !s) hipLaunchKernelGGL((panel_v6<false, 256>), dim3(nwg), dim3(256), 0, 0, d, lda, m, s);
 			if (variant == 8 && s) hipLaunchKernelGGL((panel_v8<true, 128>), dim3(nwg), dim3(128), 0, 0, d, lda, m, s);
 			if (variant == 8 && !s) hipLaunchKernelGGL((panel_v8<false, 128>), dim3(nwg), dim3(128), 0, 0, d, lda, m, s);
+			if (variant == 9 && s) hipLaunchKernelGGL((panel_v9<true>), dim3(nwg), dim3(128), 0, 0, d, lda, m, s);
+			if (variant == 9 && !s) hipLaunchKernelGGL((panel_v9<false>), dim3(nwg), dim3(128), 0, 0, d, lda, m, s);
 			if (variant == 5 && s) hipLaunchKernelGGL((panel_v3<true, 128>), dim3(nwg), dim3(128), 0, 0, d, lda, m, s);
 			if (variant == 5 && !s) hipLaunchKernelGGL((panel_v3<false, 128>), dim3(nwg), dim3(128), 0, 0, d, lda, m, s);
 			if (variant == 4 && s) hipLaunchKernelGGL((panel_v4<true>), dim3(nwg), dim3(THREADS), 0, 0, d, lda, m, s);
@@ -561,6 +780,7 @@ int main()
 		hipEventElapsedTime(&ms, e0, e1);
 		printf("variant %d: %.2f us/launch, maxdiff vs v0 %.3e, stamps(cycles from start):", variant, ms * 1000 / 50, maxdiff);
 		for (int i = 1; i < 7; ++i) printf(" %lld", hs[i] ? hs[i] - hs[0] : 0LL);
+		if (variant == 9) printf("   v9 end stamps: wave0 %lld  wave1 %lld", all[2 * nwg * nthreads + 0] - all[0], all[2 * nwg * nthreads + 64] - all[64]);
 		printf("\n");
 	}
 	return 0;
