@@ -36,6 +36,35 @@ def default_api():
     return _default_api
 
 
+class ApiPool:
+    """Several contexts on one device = several HIP streams.  The density-matrix elements are independent GPs (predict.h:89,
+    opt.cpp:518-588) and a single fit at N <= 2048 is latency-bound on a few CUs, so fitting them concurrently — element e on
+    context e mod n, one host thread each (the ctypes calls drop the GIL) — overlaps them on the GPU.  Results do not depend
+    on the pool: every element still runs the same kernels on the same data."""
+
+    def __init__(self, n=3, device=0, apis=None):
+        from concurrent.futures import ThreadPoolExecutor
+        from . import open_api
+        self.apis = list(apis) if apis is not None else [open_api(device) for _ in range(n)]
+        self._owned = apis is None
+        self._pool = ThreadPoolExecutor(max_workers=len(self.apis))
+
+    def api_for(self, index):
+        return self.apis[index % len(self.apis)]
+
+    def map(self, fn, items):
+        """fn(api, item) for every item, item i on context i mod n; results in order."""
+        futures = [self._pool.submit(fn, self.api_for(i), it) for i, it in enumerate(items)]
+        return [f.result() for f in futures]
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        if self._owned:
+            for a in self.apis:
+                a.close()
+        self.apis = []
+
+
 def _flags(err, avg, der):
     return (c.CALC_ERROR if err else 0) | (c.CALC_AVERAGE if avg else 0) | (c.CALC_DERIVATIVE if der else 0)
 
@@ -279,20 +308,27 @@ class TrainingKernels:
     def __init__(self, ParameterVectors, TrainingSets, IsToCalculateError=True, IsToCalculateAverage=True,
                  IsToCalculateDerivative=False, api=None, num_pes=None):
         self.num_pes = num_pes or NumPES
-        self._k = {}
-        for (i, j) in element_order(self.num_pes):
-            feature, label = TrainingSets[(i, j)]
-            params = ParameterVectors[(i, j)]
+
+        def build(one_api, e):
+            (i, j) = e
+            feature, label = TrainingSets[e]
+            params = ParameterVectors[e]
             if len(feature) == 0:
-                self._k[(i, j)] = None  # predict.cpp:308-315
-            elif i == j:
-                self._k[(i, j)] = TrainingKernel(params, (feature, label), IsToCalculateError, IsToCalculateAverage,
-                                                 IsToCalculateDerivative, api=api)
-            elif all(p == 0 for p in params):
-                self._k[(i, j)] = None  # predict.cpp:339-357
-            else:
-                self._k[(i, j)] = TrainingComplexKernel(params, (feature, label), IsToCalculateError, IsToCalculateAverage,
-                                                        IsToCalculateDerivative, api=api)
+                return None  # predict.cpp:308-315
+            if i == j:
+                return TrainingKernel(params, (feature, label), IsToCalculateError, IsToCalculateAverage,
+                                      IsToCalculateDerivative, api=one_api)
+            if all(p == 0 for p in params):
+                return None  # predict.cpp:339-357
+            return TrainingComplexKernel(params, (feature, label), IsToCalculateError, IsToCalculateAverage,
+                                         IsToCalculateDerivative, api=one_api)
+
+        order = element_order(self.num_pes)
+        if isinstance(api, ApiPool):  # elements on separate streams, built concurrently
+            built = api.map(build, order)
+        else:
+            built = [build(api, e) for e in order]
+        self._k = dict(zip(order, built))
 
     def __call__(self, iPES, jPES=None):
         return self._k[(iPES, iPES if jPES is None else jPES)]
@@ -404,13 +440,19 @@ def diagonal_loose(x, grad, params, api=None, num_pes=None):
     """opt.cpp:594-617: sum of loose_function over the diagonal elements on parameter slices of 4."""
     TrainingSets, ExtraTrainingSets = params
     n = num_pes or NumPES
+    active = [i for i in range(n) if len(TrainingSets[(i, i)][0]) != 0]
+
+    def one(one_api, i):
+        g = [0.0] * REAL_NPARAM if len(grad) > 0 else []
+        v = loose_function(x[i * REAL_NPARAM:(i + 1) * REAL_NPARAM], g, (TrainingSets[(i, i)], ExtraTrainingSets[(i, i)]), api=one_api)
+        return v, g
+
+    results = api.map(one, active) if isinstance(api, ApiPool) else [one(api, i) for i in active]
     err = 0.0
-    for i in range(n):
-        if len(TrainingSets[(i, i)][0]) != 0:
-            g = [0.0] * REAL_NPARAM if len(grad) > 0 else []
-            err += loose_function(x[i * REAL_NPARAM:(i + 1) * REAL_NPARAM], g, (TrainingSets[(i, i)], ExtraTrainingSets[(i, i)]), api=api)
-            if len(grad) > 0:
-                grad[i * REAL_NPARAM:(i + 1) * REAL_NPARAM] = g
+    for i, (v, g) in zip(active, results):  # summed in element order either way
+        err += v
+        if len(grad) > 0:
+            grad[i * REAL_NPARAM:(i + 1) * REAL_NPARAM] = g
     if len(grad) > 0:
         grad[:] = [make_normal(d) for d in grad]
     return make_normal(err)
@@ -438,12 +480,19 @@ def full_loose(x, grad, params, api=None, num_pes=None):
     """opt.cpp:844-870"""
     TrainingSets, ExtraTrainingSets = params
     allp = construct_all_parameters(x, num_pes)
-    err, grads = 0.0, {}
-    for e in element_order(num_pes):
+    order = element_order(num_pes)
+
+    def one(one_api, e):
         n = REAL_NPARAM if e[0] == e[1] else COMPLEX_NPARAM
-        grads[e] = [0.0] * n if len(grad) > 0 else []
-        if len(TrainingSets[e][0]) != 0:
-            err += loose_function(allp[e], grads[e], (TrainingSets[e], ExtraTrainingSets[e]), api=api)
+        g = [0.0] * n if len(grad) > 0 else []
+        v = loose_function(allp[e], g, (TrainingSets[e], ExtraTrainingSets[e]), api=one_api) if len(TrainingSets[e][0]) != 0 else 0.0
+        return v, g
+
+    results = api.map(one, order) if isinstance(api, ApiPool) else [one(api, e) for e in order]
+    err, grads = 0.0, {}
+    for e, (v, g) in zip(order, results):
+        err += v
+        grads[e] = g
     if len(grad) > 0:
         grad[:] = [make_normal(d) for d in construct_combined_parameters(grads, num_pes)]
     return make_normal(err)

@@ -218,23 +218,30 @@ class Optimization:
 
     # ---- stages ----
     def _optimize_elementwise(self, TrainingSets, ExtraTrainingSets, params, is_global):
-        """opt.cpp:518-588"""
-        total_error, num_steps = 0.0, []
-        for e in self.elements:
+        """opt.cpp:518-588.  The element searches are independent; with an ApiPool they run concurrently, one context
+        (HIP stream) and one host thread each, and return exactly what the sequential loop returns."""
+
+        def search(one_api, e):
             if len(TrainingSets[e][0]) == 0:
-                num_steps.append(0)
-                continue
+                return params[e], 0.0, 0
             etp = (TrainingSets[e], ExtraTrainingSets[e])
             lb, ub = self._bounds[e]
             try:
                 if is_global:
-                    obj = lambda x, g, etp=etp: K.loose_function_global_wrapper(x, g, etp, api=self.api)
-                    params[e], err, n = _direct(obj, params[e], K.local_parameter_to_global(lb), K.local_parameter_to_global(ub))
-                else:
-                    obj = lambda x, g, etp=etp: K.loose_function(x, g, etp, api=self.api)
-                    params[e], err, n = _nelder_mead(obj, params[e], lb, ub, self.local_maxeval)
+                    obj = lambda x, g: K.loose_function_global_wrapper(x, g, etp, api=one_api)
+                    return _direct(obj, params[e], K.local_parameter_to_global(lb), K.local_parameter_to_global(ub))
+                obj = lambda x, g: K.loose_function(x, g, etp, api=one_api)
+                return _nelder_mead(obj, params[e], lb, ub, self.local_maxeval)
             except (ArithmeticError, ValueError):  # opt.cpp:555-565: a failed search keeps what it had
-                err, n = 0.0, 0
+                return params[e], 0.0, 0
+
+        if isinstance(self.api, K.ApiPool):
+            results = self.api.map(search, self.elements)
+        else:
+            results = [search(self.api, e) for e in self.elements]
+        total_error, num_steps = 0.0, []
+        for e, (x, err, n) in zip(self.elements, results):
+            params[e] = x
             total_error += err
             num_steps.append(n)
         return total_error, num_steps
@@ -260,6 +267,9 @@ class Optimization:
         x, err, steps = _auglag_eq(obj, con, 3, x0, self._stack(0, False), self._stack(1, False))
         params.update(K.construct_all_parameters(x, n))
         return err, [steps]
+
+    def _one_api(self):
+        return self.api.api_for(0) if isinstance(self.api, K.ApiPool) else self.api
 
     def _kernels(self, params, TrainingSets):
         return K.TrainingKernels(params, TrainingSets, False, True, False, api=self.api, num_pes=self.num_pes)
@@ -300,7 +310,7 @@ class Optimization:
             for e in self.elements:  # afterwards, the magnitude (opt.cpp:1179-1196)
                 if len(TrainingSets[e][0]) != 0:
                     cls = K.TrainingKernel if e[0] == e[1] else K.TrainingComplexKernel
-                    params[e][0] = cls(params[e], TrainingSets[e], False, False, False, api=self.api).get_magnitude()
+                    params[e][0] = cls(params[e], TrainingSets[e], False, False, False, api=self._one_api()).get_magnitude()
             return [err, steps, opt_type]
 
         def beyond_tolerance_error(calc, ref):  # opt.cpp:1212-1223

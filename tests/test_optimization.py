@@ -118,3 +118,33 @@ def test_optimization_driver_with_offdiagonal_element(gpu):
     ks = K.TrainingKernels(p, K.construct_training_sets(density), False, True, False, api=gpu)
     assert abs(ks.calculate_population() - 1.0) < 2 * O.AverageTolerance
     assert abs(ks.calculate_purity() - 1.0) < 2 * O.AverageTolerance
+
+
+@pytest.mark.gpu
+def test_api_pool_gives_the_same_kernels_and_the_same_optimum(gpu):
+    """Elements on separate contexts / HIP streams / host threads: same numbers as one after the other."""
+    density = _density(160, offdiag=True)
+    ts = K.construct_training_sets(density)
+    pv = {(0, 0): [1.0, 0.9, 0.45, 1e-2], (1, 0): [1.0, 1.1, 0.9, 0.45, 0.9, 1.0, 0.5, 1e-2], (1, 1): [1.0, 0.8, 0.5, 1e-2]}
+    pool = K.ApiPool(3)
+    try:
+        a = K.TrainingKernels(pv, ts, True, True, True, api=gpu)
+        b = K.TrainingKernels(pv, ts, True, True, True, api=pool)
+        assert a.calculate_population() == b.calculate_population() and a.calculate_purity() == b.calculate_purity()
+        assert np.array_equal(a.purity_derivative(), b.purity_derivative())
+        assert np.array_equal(a(1, 0).get_error_derivative(), b(1, 0).get_error_derivative())
+        empty = K.construct_training_sets({})
+        g1, g2 = [0.0] * 16, [0.0] * 16
+        x = K.construct_combined_parameters(pv)
+        assert K.full_loose(x, g1, (ts, empty), api=gpu) == K.full_loose(x, g2, (ts, empty), api=pool) and g1 == g2
+        e0 = O.calculate_total_energy_average_one_surface(density[(0, 0)], MASS, 0)
+        res = []
+        for api in (gpu, pool):
+            opt = O.Optimization(SIGMA, (-6.0, 4.0), (6.0, 16.0), MASS, e0, 1.0, api=api, local_maxeval=60)
+            err, steps, kind = opt.optimize(density, {})
+            res.append((err, steps, opt.get_parameters()))
+        assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+        for e in res[0][2]:
+            assert list(res[0][2][e]) == list(res[1][2][e])
+    finally:
+        pool.close()
