@@ -316,7 +316,9 @@ namespace gple
 		g.A = T, g.lda = ldt, g.B = T, g.ldb = ldt, g.C = W, g.ldc = ldw;
 		g.M = n, g.N = n, g.K = n, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
 		g.krange = K_GE_MAX_MN, g.lower_only = 1, g.a_kmajor = true, g.b_kmajor = true, g.c_trans = false;
-		hipError_t e = launch_gemm(s, g, pick_tile(n, n, 1));
+		// the k-range of tile (m0, n0) starts at max(m0, n0): the work per tile is very uneven and the first tile column
+		// carries the full K, so small tiles (4x shorter critical path) win until the matrix is large
+		hipError_t e = launch_gemm(s, g, n >= 8192 ? 128 : 64);
 		if (e != hipSuccess) return e;
 		hipLaunchKernelGGL(mirror_lower_kernel, dim3(n / 32, n / 32), dim3(256), 0, s, W, ldw, n);
 		return hipGetLastError();

@@ -42,7 +42,14 @@ namespace gple
 		constexpr int BS = BN + 16; // LDS row stride of the T tile [k][n]
 		constexpr int A_SLAB = BK * AS, B_SLAB = BK * BS;
 		constexpr int NTHREADS = 512;
-		constexpr int GEN_KSPLIT = 8; // k-ranges per row in the generation kernel (partial means)
+		constexpr int GEN_KSPLIT_MIN = 8, GEN_KSPLIT_MAX = 64; // k-ranges per row in the generation kernel (partial means)
+		// few test rows: split k further so that the generation still fills the chip (>= ~512 workgroups of 128 rows)
+		int gen_ksplit(int m_rows)
+		{
+			int ks = GEN_KSPLIT_MIN;
+			while (ks < GEN_KSPLIT_MAX && static_cast<long>(m_rows / 128) * ks < 512) ks *= 2;
+			return ks;
+		}
 
 		// exp(x) for finite x <= 0 (the argument of a squared-exponential kernel), fp64, < 1 ulp:
 		// x = k ln2 + r (Cody-Waite with an FMA), |r| <= ln2/2, degree-12 Taylor/Horner, scaling by v_ldexp_f64 (which
@@ -73,7 +80,7 @@ namespace gple
 		// typed test set -> Ks (column-major, ld = rows); partial means mu_part[ky][row] = sum_{k in range ky} K* v[k].
 		// One thread per row, blockIdx.y selects the k-range; the training point of each k is a scalar load.
 		// DERIV (real GP only): also accumulates K* dv_ip (ip = 0..3) and (dK*/dl_d) v (d = 0, 1) per row for
-		// PredictiveKernel::ErrorDerivatives (kernel.cpp:524-542); mu_part then holds 7 planes of GEN_KSPLIT x m_rows.
+		// PredictiveKernel::ErrorDerivatives (kernel.cpp:524-542); mu_part then holds 7 planes of gridDim.y x m_rows.
 		// DERIV = 2 (complex GP in the [Re; Im] embedding): 15 planes [c w, c dw_0..7, dc_1..6 w] for
 		// PredictiveComplexKernel::ErrorDerivatives (complex_kernel.cpp:648-668); dc_p comes from a.dspec[p - 1].
 		template <int DERIV>
@@ -86,7 +93,8 @@ namespace gple
 			int pidx = type_m ? gm - a.m_split : gm;
 			pidx = pidx < a.M ? pidx : a.M - 1; // rows beyond M are clamped (their results are never read)
 			const double xm = a.Xs[2 * pidx], pm = a.Xs[2 * pidx + 1];
-			const int kper = a.n_total / GEN_KSPLIT; // multiple of 32 (n_total is a multiple of 256)
+			const int ksplit = gridDim.y;
+			const int kper = a.n_total / ksplit; // multiple of 4 (n_total is a multiple of 256, ksplit <= 64)
 			const int kbeg = blockIdx.y * kper;
 			double mu = 0.0;
 			constexpr int NACC = DERIV == 2 ? 14 : 6;
@@ -143,7 +151,7 @@ namespace gple
 			mu_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = mu;
 			if constexpr (DERIV != 0)
 #pragma unroll
-				for (int ip = 0; ip < NACC; ++ip) mu_part[(static_cast<long>(ip + 1) * GEN_KSPLIT + blockIdx.y) * a.m_rows + gm] = dacc[ip];
+				for (int ip = 0; ip < NACC; ++ip) mu_part[(static_cast<long>(ip + 1) * ksplit + blockIdx.y) * a.m_rows + gm] = dacc[ip];
 		}
 
 		// the k-steps that cross the diagonal 256-block of an N-tile: step D starts at k = n0 + KB D, where the column blocks
@@ -265,14 +273,13 @@ namespace gple
 		}
 
 		// plane blockIdx.y of the partial sums -> out[plane][row]
-		__global__ void __launch_bounds__(256) sum_mu_kernel(const double* __restrict__ mu_part, int m_rows, double* __restrict__ out)
+		__global__ void __launch_bounds__(256) sum_mu_kernel(const double* __restrict__ mu_part, int m_rows, int ksplit, double* __restrict__ out)
 		{
 			const int i = blockIdx.x * 256 + threadIdx.x;
 			if (i >= m_rows) return;
-			const double* __restrict__ p = mu_part + static_cast<long>(blockIdx.y) * GEN_KSPLIT * m_rows;
+			const double* __restrict__ p = mu_part + static_cast<long>(blockIdx.y) * ksplit * m_rows;
 			double s = 0.0;
-#pragma unroll
-			for (int ky = 0; ky < GEN_KSPLIT; ++ky) s += p[static_cast<long>(ky) * m_rows + i];
+			for (int ky = 0; ky < ksplit; ++ky) s += p[static_cast<long>(ky) * m_rows + i];
 			out[static_cast<long>(blockIdx.y) * m_rows + i] = s;
 		}
 		// q[m] = sum_n Z(n, m)^2 (column m of the n x rows matrix Z = T K*^T): one workgroup per test row
@@ -313,7 +320,7 @@ namespace gple
 		if (rows > static_cast<size_t>(a.m_rows)) rows = a.m_rows;
 		if (small_m(a)) rows = a.m_rows; // one chunk (<= 512 MiB), plus Z of the same size
 		*chunk_rows = static_cast<int>(rows);
-		return rows * a.n_total + static_cast<size_t>(GEN_KSPLIT) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1)
+		return rows * a.n_total + static_cast<size_t>(gen_ksplit(a.m_rows)) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1)
 			+ (small_m(a) ? rows * a.n_total : 0);
 	}
 
@@ -329,11 +336,12 @@ namespace gple
 		double* Ks = scratch;
 		double* mu_part = scratch + static_cast<size_t>(chunk_rows) * a.n_total;
 		const bool small = small_m(a) && chunk_rows == a.m_rows;
-		double* Z = mu_part + static_cast<size_t>(GEN_KSPLIT) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1);
+		const int ksplit = gen_ksplit(a.m_rows);
+		double* Z = mu_part + static_cast<size_t>(ksplit) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1);
 		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
 		{
 			const int rows = a.m_rows - row0 < chunk_rows ? a.m_rows - row0 : chunk_rows;
-			const dim3 ggrid(rows / 128, GEN_KSPLIT);
+			const dim3 ggrid(rows / 128, ksplit);
 			if (a.dv && a.complex_deriv) hipLaunchKernelGGL(kstar_gen_kernel<2>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
 			else if (a.dv) hipLaunchKernelGGL(kstar_gen_kernel<1>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
 			else hipLaunchKernelGGL(kstar_gen_kernel<0>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
@@ -355,8 +363,8 @@ namespace gple
 			chunk_timer_stop(ctx);
 		}
 		// a.mu receives plane 0 (the mean); with derivatives a.dacc receives all 7 planes (plane 0 = the mean again)
-		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, a.mu);
-		if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, a.complex_deriv ? 15 : 7), dim3(256), 0, s, mu_part, a.m_rows, a.dacc);
+		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.mu);
+		if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, a.complex_deriv ? 15 : 7), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.dacc);
 		return hipGetLastError();
 	}
 } // namespace gple

@@ -275,7 +275,10 @@ def test_concurrent_predicts_on_one_fit(gpu):
     import threading
     X, y, Xs = parity.synthetic_real(300, 2000, 81)
     fit = gpu.real_fit([1.0, 0.7086, 0.7056, 1e-2], X, y, 1)
-    ref = gpu.real_predict(fit, Xs)
+    # reference: the same four slices one after the other (the split of the mean's k-sum depends on the row count of a call,
+    # so a slice is compared with the same slice, bit for bit)
+    ref = [gpu.real_predict(fit, Xs[i * 500:(i + 1) * 500]) for i in range(4)]
+    whole = gpu.real_predict(fit, Xs)
     out, errs = {}, []
 
     def work(i):
@@ -292,7 +295,9 @@ def test_concurrent_predicts_on_one_fit(gpu):
     assert not errs
     for i in range(4):
         sl = slice(i * 500, (i + 1) * 500)
-        assert np.array_equal(out[i]["prediction"], ref["prediction"][sl]) and np.array_equal(out[i]["variance"], ref["variance"][sl])
+        assert np.array_equal(out[i]["prediction"], ref[i]["prediction"]) and np.array_equal(out[i]["variance"], ref[i]["variance"])
+        assert np.abs(out[i]["prediction"] - whole["prediction"][sl]).max() <= 1e-13 * np.abs(whole["prediction"]).max()
+        assert np.abs(out[i]["variance"] - whole["variance"][sl]).max() <= 1e-12
 
 
 def test_complex_edge_cases(gpu, oracle):
