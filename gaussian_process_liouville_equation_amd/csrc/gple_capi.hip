@@ -318,7 +318,7 @@ namespace
 			g.A = Dd, g.lda = nt, g.B = f->W, g.ldb = nt, g.C = C.p, g.ldc = nt;
 			g.M = nt, g.N = nt, g.K = nt, g.batch = 1, g.alpha = 1.0, g.beta = 0.0, g.krange = K_FULL, g.lower_only = 0;
 			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
-			GPLE_HIP(ctx, launch_gemm(st, g, (nt / 128) * (nt / 128) >= 256 ? 128 : 64));
+			GPLE_HIP(ctx, launch_gemm(st, g, gemm_pick_tile(nt, nt, 1, false)));
 			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, C.p, nt, nt, 0, -1.0, dwd.p + static_cast<size_t>(1 + d) * nt));
 		}
 		// noise: dW = -2 sf^2 sn W W (:358)
@@ -425,7 +425,7 @@ namespace
 			g.A = D.p, g.lda = nt, g.B = f->W, g.ldb = nt, g.C = C.p, g.ldc = nt;
 			g.M = nt, g.N = nt, g.K = nt, g.batch = 1, g.alpha = 1.0, g.beta = 0.0, g.krange = K_FULL, g.lower_only = 0;
 			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
-			GPLE_HIP(ctx, launch_gemm(st, g, (nt / 128) * (nt / 128) >= 256 ? 128 : 64));
+			GPLE_HIP(ctx, launch_gemm(st, g, gemm_pick_tile(nt, nt, 1, false)));
 			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, C.p, nt, nt, 0, -1.0, dwd.p + static_cast<size_t>(ip) * nt));
 			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, C.p, nt, nt, Np, -1.0, dwx.p + static_cast<size_t>(ip) * Np));
 		}

@@ -228,11 +228,6 @@ namespace gple
 			}
 		}
 
-		int pick_tile(long m, long n, long batch)
-		{
-			if (m % 128 || n % 128) return 64;
-			return (m / 128) * (n / 128) * batch >= 256 ? 128 : 64;
-		}
 	} // namespace
 
 	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info)
@@ -251,7 +246,7 @@ namespace gple
 			g.A = P, g.lda = lda, g.B = P, g.ldb = lda, g.C = A + (j0 + NB) + static_cast<long>(j0 + NB) * lda, g.ldc = lda;
 			g.M = below, g.N = below, g.K = NB, g.batch = 1, g.alpha = -1.0, g.beta = 1.0, g.krange = K_FULL, g.lower_only = 1;
 			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
-			const hipError_t e = launch_gemm(s, g, pick_tile(below, below, 1) == 128 && below >= 2048 ? 128 : 64);
+			const hipError_t e = launch_gemm(s, g, gemm_pick_tile(below, below, 1, true));
 			if (e != hipSuccess) return e;
 		}
 		// the 64 x 64 inverses are only the leaves of the merge tree: one batched launch, off the factorisation's critical path
@@ -292,7 +287,7 @@ namespace gple
 				g.C = work, g.ldc = s2, g.strideC = static_cast<long>(s1) * s2;
 				g.M = s2, g.N = s1, g.K = s1, g.batch = count, g.alpha = 1.0, g.beta = 0.0;
 				g.krange = K_GE_N, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
-				const int tile = pick_tile(s2, s1, count);
+				const int tile = gemm_pick_tile(s2, s1, count, true);
 				hipError_t e = launch_gemm(s, g, tile);
 				if (e != hipSuccess) return e;
 				// T21_b = - T22_b * W_b
@@ -318,7 +313,7 @@ namespace gple
 		g.krange = K_GE_MAX_MN, g.lower_only = 1, g.a_kmajor = true, g.b_kmajor = true, g.c_trans = false;
 		// the k-range of tile (m0, n0) starts at max(m0, n0): the work per tile is very uneven and the first tile column
 		// carries the full K, so small tiles (4x shorter critical path) win until the matrix is large
-		hipError_t e = launch_gemm(s, g, n >= 8192 ? 128 : 64);
+		hipError_t e = launch_gemm(s, g, gemm_pick_tile(n, n, 1, true));
 		if (e != hipSuccess) return e;
 		hipLaunchKernelGGL(mirror_lower_kernel, dim3(n / 32, n / 32), dim3(256), 0, s, W, ldw, n);
 		return hipGetLastError();

@@ -15,6 +15,8 @@
 //   second operand Y[k = lane >> 4][j = lane & 15]   (4 x 16),
 //   result         D[i = (lane >> 4) + 4 * reg][j = lane & 15].
 // The operand that should end up contiguous in memory is therefore fed as the SECOND operand.
+#include <cstdlib>
+
 #include "gple_internal.h"
 
 namespace gple
@@ -328,6 +330,23 @@ namespace gple
 			return hipErrorInvalidValue;
 		}
 	} // namespace
+
+	int gemm_pick_tile(long m, long n, long batch, bool triangular)
+	{
+		// 128-tiles (4 waves, 16 accumulator tiles each) need at least two workgroups per CU to cover their LDS latency;
+		// below that the 64-tile kernel with its deeper prefetch and 4x more workgroups is faster.  Triangular work (lower
+		// tiles only, or a k-range that depends on the tile) is uneven per tile, so small tiles stay ahead much longer.
+		static const long min_dense = [] {
+			const char* e = getenv("GPLE_GEMM_128_MIN_TILES");
+			return e ? atol(e) : 512L;
+		}();
+		static const long min_tri = [] {
+			const char* e = getenv("GPLE_GEMM_128_MIN_TILES_TRI");
+			return e ? atol(e) : 4096L;
+		}();
+		if (m % 128 || n % 128) return 64;
+		return (m / 128) * (n / 128) * batch >= (triangular ? min_tri : min_dense) ? 128 : 64;
+	}
 
 	hipError_t launch_gemm(hipStream_t s, const GemmDesc& d, int tile)
 	{

@@ -128,6 +128,8 @@ namespace gple
 	};
 	// tile: 64 (64x64 per workgroup) or 128 (128x128 per workgroup)
 	hipError_t launch_gemm(hipStream_t s, const GemmDesc& d, int tile);
+	// tile size for an m x n (x batch) result: 128 once there are enough 128-tiles to give every CU two workgroups
+	int gemm_pick_tile(long m, long n, long batch, bool triangular);
 
 	// ---- dense factorisation drivers (gple_chol.hip) -------------------------------------------------------
 	// In-place lower Cholesky of the n x n (n multiple of CHOL_NB) column-major matrix A; the strictly upper part

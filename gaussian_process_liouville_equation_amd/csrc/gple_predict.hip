@@ -353,8 +353,7 @@ namespace gple
 				g.M = a.n_total, g.N = rows, g.K = a.n_total, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
 				g.krange = K_LE_M; // T(n, k) = 0 for k > n
 				g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
-				const bool big_tiles = static_cast<long>(a.n_total / 128) * (rows / 128) >= 256;
-				const hipError_t e = launch_gemm(s, g, big_tiles ? 128 : 64);
+				const hipError_t e = launch_gemm(s, g, gemm_pick_tile(a.n_total, rows, 1, true));
 				if (e != hipSuccess) return e;
 				hipLaunchKernelGGL(colsumsq_kernel, dim3(rows), dim3(256), 0, s, Z, static_cast<long>(a.n_total), a.n_total, a.q + row0);
 			}
