@@ -961,9 +961,10 @@ extern "C"
 			if (cplx) std::memcpy(a.dspec, f->dspec, sizeof(a.dspec));
 		}
 		int chunk_rows = 0;
+		bool few_rows = false;
 		Scratch kstar(ctx);
-		GPLE_HIP(ctx, kstar.get(predict_scratch_doubles(a, &chunk_rows)));
-		GPLE_HIP(ctx, launch_predict_q(ctx, st, a, kstar.p, chunk_rows));
+		GPLE_HIP(ctx, kstar.get(predict_scratch_doubles(a, &chunk_rows, &few_rows)));
+		GPLE_HIP(ctx, launch_predict_q(ctx, st, a, kstar.p, chunk_rows, few_rows));
 		const double* lab_dev = labels;
 		if (labels && !dev)
 		{

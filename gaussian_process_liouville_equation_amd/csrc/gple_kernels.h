@@ -129,9 +129,9 @@ namespace gple
 	// Rolling K* scratch of the predict path (HBM): bounded so that M x N never has to exist at once.
 	constexpr size_t PREDICT_SCRATCH_BYTES = size_t(4) << 30;
 	// doubles of scratch launch_predict_q needs for `a`; *chunk_rows = rows of the typed test set handled per pass
-	size_t predict_scratch_doubles(const PredictArgs& a, int* chunk_rows);
+	size_t predict_scratch_doubles(const PredictArgs& a, int* chunk_rows, bool* few_rows);
 	// fills a.q and a.mu; per chunk: kstar_gen_kernel then rownorm_kernel (bracketed by the context's chunk timers)
-	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows);
+	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows, bool few_rows);
 	// real finish: var = self - q, cutoff, cut = mu*cf/s ; optional labels -> err_out[0] += sum (mu - s t)^2
 	hipError_t launch_predict_finish_real(hipStream_t s, const double* q, const double* mu, int M, double self, const double* s_dev,
 		const double* labels, double* mean, double* var, double* cut, double* err_out);

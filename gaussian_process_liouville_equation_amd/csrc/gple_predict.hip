@@ -311,20 +311,22 @@ namespace gple
 		}
 	} // namespace
 
-	size_t predict_scratch_doubles(const PredictArgs& a, int* chunk_rows)
+	size_t predict_scratch_doubles(const PredictArgs& a, int* chunk_rows, bool* few_rows)
 	{
 		// rolling K* chunk: as many 128-row tiles as fit PREDICT_SCRATCH_BYTES (at least one), never more than needed
 		const size_t per_row = static_cast<size_t>(a.n_total) * sizeof(double);
 		size_t rows = PREDICT_SCRATCH_BYTES / per_row / BM * BM;
 		if (rows < static_cast<size_t>(BM)) rows = BM;
 		if (rows > static_cast<size_t>(a.m_rows)) rows = a.m_rows;
-		if (small_m(a)) rows = a.m_rows; // one chunk (<= 512 MiB), plus Z of the same size
+		const bool small = small_m(a); // decided once per call: launch_predict_q gets the same answer
+		*few_rows = small;
+		if (small) rows = a.m_rows; // one chunk (<= 512 MiB), plus Z of the same size
 		*chunk_rows = static_cast<int>(rows);
 		return rows * a.n_total + static_cast<size_t>(gen_ksplit(a.m_rows)) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1)
-			+ (small_m(a) ? rows * a.n_total : 0);
+			+ (small ? rows * a.n_total : 0);
 	}
 
-	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows)
+	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows, bool few_rows)
 	{
 		if (a.M <= 0) return hipSuccess;
 		if (a.m_rows % BM || a.n_total % BN || a.m_split % BM || a.n_split % BN || chunk_rows % BM || chunk_rows <= 0)
@@ -335,7 +337,7 @@ namespace gple
 		}();
 		double* Ks = scratch;
 		double* mu_part = scratch + static_cast<size_t>(chunk_rows) * a.n_total;
-		const bool small = small_m(a) && chunk_rows == a.m_rows;
+		const bool small = few_rows && chunk_rows == a.m_rows;
 		const int ksplit = gen_ksplit(a.m_rows);
 		double* Z = mu_part + static_cast<size_t>(ksplit) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1);
 		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
