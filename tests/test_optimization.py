@@ -148,3 +148,28 @@ def test_api_pool_gives_the_same_kernels_and_the_same_optimum(gpu):
             assert list(res[0][2][e]) == list(res[1][2][e])
     finally:
         pool.close()
+
+
+def test_api_pool_host_logic_on_oracle(oracle):
+    """The pool's dispatch (element e -> context e mod n, results in element order) exercised on CPU with two handles of the
+    checker standing in for two device contexts."""
+    density = _density(40, offdiag=True)
+    ts = K.construct_training_sets(density)
+    pv = {(0, 0): [1.0, 0.9, 0.45, 1e-2], (1, 0): [1.0, 1.1, 0.9, 0.45, 0.9, 1.0, 0.5, 1e-2], (1, 1): [1.0, 0.8, 0.5, 1e-2]}
+    pool = K.ApiPool(apis=[oracle, oracle])
+    try:
+        assert pool.api_for(0) is oracle and pool.api_for(3) is oracle
+        assert pool.map(lambda api, item: (api is oracle, item * 2), [1, 2, 3]) == [(True, 2), (True, 4), (True, 6)]
+        a = K.TrainingKernels(pv, ts, True, True, True, api=oracle)
+        b = K.TrainingKernels(pv, ts, True, True, True, api=pool)
+        assert a.calculate_population() == b.calculate_population() and a.calculate_purity() == b.calculate_purity()
+        assert np.array_equal(a.purity_derivative(), b.purity_derivative())
+        empty = K.construct_training_sets({})
+        x = K.construct_combined_parameters(pv)
+        g1, g2 = [0.0] * 16, [0.0] * 16
+        assert K.full_loose(x, g1, (ts, empty), api=oracle) == K.full_loose(x, g2, (ts, empty), api=pool) and g1 == g2
+        d1, d2 = [0.0] * 8, [0.0] * 8
+        xd = pv[(0, 0)] + pv[(1, 1)]
+        assert K.diagonal_loose(xd, d1, (ts, empty), api=oracle) == K.diagonal_loose(xd, d2, (ts, empty), api=pool) and d1 == d2
+    finally:
+        pool.close()  # handles passed in are not closed by the pool
