@@ -190,7 +190,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: N={N} samples, {G}x{G} grid (M={M}), {kernel} SE kernel, fit(error+average) + grid predict(mean,var,cutoff)",
-                   "N": N, "M": M, "parallelism": f"grid-sharded x{world}, replicated fit, RCCL all-gather" if world > 1 else "single GPU"},
+                   "N": N, "M": M, "parallelism": f"grid-sharded x{world}, replicated fit, {'RCCL' if args.backend == 'nccl' else 'gloo (host)'} all-gather" if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "kernel": "rownorm_kernel (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
                      "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
                      "traffic": traffic, "kernel_ms": round(pk_ms, 4), "launches_per_step": launches_per_step,
