@@ -168,7 +168,7 @@ namespace gple
 		// GPLE_ROWNORM_VARIANT for A/B runs, default chosen in launch_predict_q).
 		template <int WAVES, int KB>
 		__global__ void __launch_bounds__(WAVES * 64, 8 / WAVES) rownorm_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T,
-			long ldt, int n_total, double* __restrict__ q)
+			long ldt, int n_total, double* __restrict__ q, long qstride)
 		{
 			constexpr int TM = WAVES * 16, NT = WAVES * 64;
 			constexpr int ASr = TM + 16;
@@ -222,8 +222,14 @@ namespace gple
 				}
 			};
 
+			// gridDim.y > 1 splits the N-tiles of one row block over several workgroups (few row blocks: fill the chip anyway).
+			// N-tile jt costs jt + 1 units, so the tiles are dealt out in snake order: group g of G takes the tiles whose
+			// position in a period of 2 G is g or 2 G - 1 - g.
+			const int G = gridDim.y, g = blockIdx.y;
 			for (int jt = 0; jt < ntiles; ++jt)
 			{
+				const int pos = jt % (2 * G);
+				if ((pos < G ? pos : 2 * G - 1 - pos) != g) continue; // uniform; no accumulator is live here
 				const int n0 = jt * BN;
 				const int nk = (n0 + BN) / KB; // T(n,k) = 0 for k > n: k-slabs beyond the N-tile's last column are skipped
 				d4 acc[16];
@@ -269,7 +275,7 @@ namespace gple
 			}
 			rsq += __shfl_xor(rsq, 16);
 			rsq += __shfl_xor(rsq, 32);
-			if (lane < 16) q[m0 + w * 16 + lane] = rsq;
+			if (lane < 16) q[static_cast<long>(g) * qstride + m0 + w * 16 + lane] = rsq; // partial sums of tile group g
 		}
 
 		// plane blockIdx.y of the partial sums -> out[plane][row]
@@ -297,17 +303,28 @@ namespace gple
 		}
 
 		// Few test rows (the extra-point sets of the objective, opt.cpp:441-482; single-point lookups): rownorm_kernel
-		// gives every 128 rows to ONE workgroup that walks all of T — N^2/2 k-steps on 1 of 256 CUs, 0.55 ms at N = 1024 no
-		// matter how few rows there are.  Below SMALL_M_WGS row blocks the contraction is spread over (n/64) x (rows/64)
-		// tiles instead: Z = T K*^T by the triangular-K GEMM, then column sums of squares.
-		constexpr int SMALL_M_WGS = 96;
+		// gives every 128 rows to one workgroup that walks its share of T, at best 1/8 of it (rownorm_split) — with a
+		// handful of row blocks that still leaves most CUs idle.  There the contraction is spread over (n/64) x (rows/64)
+		// tiles instead: Z = T K*^T by the triangular-K GEMM, then column sums of squares.  Measured crossover
+		// (probes/predict_path_crossover.py): about 4096 rows at N = 1024, 2048 rows at N = 4096.
+		constexpr int SMALL_M_WORK = 160; // row blocks x N-tiles
 		constexpr size_t SMALL_M_Z_DOUBLES = size_t(1) << 26; // 512 MiB of Z at most
+		// tile groups per row block for the streaming kernel: 1 once every CU has two workgroups, otherwise the smallest
+		// power of two that gets there; every group needs a snake pair of N-tiles
+		constexpr int ROWNORM_SPLIT_MAX = 8;
+		int rownorm_split(int m_rows, int n_total)
+		{
+			const int blocks = m_rows / BM, ntiles = n_total / BN;
+			int g = 1;
+			while (g < ROWNORM_SPLIT_MAX && blocks * g < 512 && 2 * (2 * g) <= ntiles) g *= 2;
+			return g;
+		}
 		bool small_m(const PredictArgs& a)
 		{
 			const bool fits = static_cast<size_t>(a.m_rows) * a.n_total <= SMALL_M_Z_DOUBLES;
 			const char* force = getenv("GPLE_PREDICT_SMALL_M"); // "0" / "1": A/B runs and the path-against-path parity test
 			if (force && (force[0] == '0' || force[0] == '1')) return force[0] == '1' && fits;
-			return a.m_rows / BM <= SMALL_M_WGS && fits;
+			return static_cast<long>(a.m_rows / BM) * (a.n_total / BN) <= SMALL_M_WORK && fits;
 		}
 	} // namespace
 
@@ -323,7 +340,7 @@ namespace gple
 		if (small) rows = a.m_rows; // one chunk (<= 512 MiB), plus Z of the same size
 		*chunk_rows = static_cast<int>(rows);
 		return rows * a.n_total + static_cast<size_t>(gen_ksplit(a.m_rows)) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1)
-			+ (small ? rows * a.n_total : 0);
+			+ (small ? rows * a.n_total : 0) + static_cast<size_t>(ROWNORM_SPLIT_MAX) * a.m_rows;
 	}
 
 	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows, bool few_rows)
@@ -340,6 +357,8 @@ namespace gple
 		const bool small = few_rows && chunk_rows == a.m_rows;
 		const int ksplit = gen_ksplit(a.m_rows);
 		double* Z = mu_part + static_cast<size_t>(ksplit) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1);
+		const int split = small ? 1 : rownorm_split(a.m_rows, a.n_total);
+		double* qpart = Z + (small ? static_cast<size_t>(chunk_rows) * a.n_total : 0);
 		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
 		{
 			const int rows = a.m_rows - row0 < chunk_rows ? a.m_rows - row0 : chunk_rows;
@@ -359,10 +378,18 @@ namespace gple
 				if (e != hipSuccess) return e;
 				hipLaunchKernelGGL(colsumsq_kernel, dim3(rows), dim3(256), 0, s, Z, static_cast<long>(a.n_total), a.n_total, a.q + row0);
 			}
-			else if (variant == 1) hipLaunchKernelGGL((rownorm_kernel<4, 8>), dim3(rows / 64), dim3(256), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
-			else hipLaunchKernelGGL((rownorm_kernel<8, 16>), dim3(rows / BM), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0);
+			else if (variant == 1) hipLaunchKernelGGL((rownorm_kernel<4, 8>), dim3(rows / 64), dim3(256), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0, 0L);
+			else
+			{
+				// fewer than two workgroups per CU: split the N-tiles of every row block over G workgroups (partial sums)
+				const int G = split;
+				double* qdst = G > 1 ? qpart + row0 : a.q + row0;
+				hipLaunchKernelGGL((rownorm_kernel<8, 16>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst,
+					static_cast<long>(a.m_rows));
+			}
 			chunk_timer_stop(ctx);
 		}
+		if (split > 1) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, qpart, a.m_rows, split, a.q);
 		// a.mu receives plane 0 (the mean); with derivatives a.dacc receives all 7 planes (plane 0 = the mean again)
 		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.mu);
 		if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, a.complex_deriv ? 15 : 7), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.dacc);
