@@ -309,15 +309,22 @@ namespace gple
 		// (probes/predict_path_crossover.py): about 4096 rows at N = 1024, 2048 rows at N = 4096.
 		constexpr int SMALL_M_WORK = 160; // row blocks x N-tiles
 		constexpr size_t SMALL_M_Z_DOUBLES = size_t(1) << 26; // 512 MiB of Z at most
-		// tile groups per row block for the streaming kernel: 1 once every CU has two workgroups, otherwise the smallest
-		// power of two that gets there; every group needs a snake pair of N-tiles
+		// Tile groups per row block for the streaming kernel.  One workgroup per CU at a time (LDS), so a launch takes
+		// ceil(blocks G / 256) rounds of 1/G the length: G is the power of two that minimises that (a little is charged per
+		// extra group for the partial sums); every group needs a snake pair of N-tiles.
 		constexpr int ROWNORM_SPLIT_MAX = 8;
 		int rownorm_split(int m_rows, int n_total)
 		{
-			const int blocks = m_rows / BM, ntiles = n_total / BN;
-			int g = 1;
-			while (g < ROWNORM_SPLIT_MAX && blocks * g < 512 && 2 * (2 * g) <= ntiles) g *= 2;
-			return g;
+			const long blocks = m_rows / BM, ntiles = n_total / BN;
+			int best = 1;
+			double best_cost = 1e300;
+			for (int g = 1; g <= ROWNORM_SPLIT_MAX; g *= 2)
+			{
+				if (g > 1 && 4 * g > 2 * ntiles) break; // fewer than one snake pair per group
+				const double cost = static_cast<double>((blocks * g + 255) / 256) / g * (1.0 + 0.02 * (g - 1));
+				if (cost < best_cost - 1e-12) best_cost = cost, best = g;
+			}
+			return best;
 		}
 		bool small_m(const PredictArgs& a)
 		{
