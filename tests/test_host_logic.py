@@ -126,3 +126,28 @@ def test_batched_distribution_matches_pointwise(oracle):
     assert np.allclose(q.result(t1), batch[:5]) and np.allclose(q.result(t3), batch[5:6])
     ref = K.PredictiveComplexKernel(gc["Xs"][:4], ks(1, 0), False).get_cutoff_prediction()
     assert np.allclose(q.result(t2), ref, rtol=0, atol=1e-15)
+
+
+def test_output_writers_layout(oracle):
+    """N4: phase.txt / var.txt / param.txt line structure (output.cpp:120-133, 180-232) on a tiny case evaluated by the oracle."""
+    import io
+    from gaussian_process_liouville_equation_amd import kernels as K, optimization as O, output
+    rng = np.random.default_rng(3)
+    r = rng.normal(size=(30, 2)) * (1.0, 0.5) + (0.0, 10.0)
+    rho = np.exp(-0.5 * (((r - (0.0, 10.0)) / (1.0, 0.5)) ** 2).sum(axis=1)) / math.pi
+    ts = K.construct_training_sets({(0, 0): (r, rho.astype(complex)), (1, 0): (r, 0.3j * rho)})
+    pv = {(0, 0): [1.0, 1.0, 0.5, 1e-2], (1, 0): [1.0, 1.0, 1.0, 0.5, 1.0, 1.0, 0.5, 1e-2], (1, 1): [1.0, 1.0, 0.5, 1e-2]}
+    ks = K.TrainingKernels(pv, ts, False, True, False, api=oracle)
+    grid = np.stack(np.meshgrid(np.linspace(-2, 2, 5), np.linspace(8, 12, 4), indexing="ij"), axis=-1).reshape(-1, 2)
+    ph, va = io.StringIO(), io.StringIO()
+    output.output_phase(ph, va, ks, grid)
+    pl, vl = ph.getvalue().split("\n"), va.getvalue().split("\n")
+    assert len(pl) == 3 * 2 + 2 and pl[-1] == "" and pl[-2] == "" and len(vl) == 3 + 2
+    assert all(len(line.split()) == 20 for line in pl[:6] + vl[:3])
+    assert set(pl[1].split()) == {"0"} and set(pl[4].split()) == {"0"} and set(pl[5].split()) == {"0"}  # Im rho00; rho11 absent
+    assert any(float(x) != 0 for x in pl[3].split())  # Im rho10
+    opt = O.Optimization((1.0, 0.5), (-6.0, 4.0), (6.0, 16.0), 2000.0, 0.025, 1.0, api=oracle)
+    f = io.StringIO()
+    output.output_param(f, opt)
+    lines = f.getvalue().split("\n")
+    assert len(lines) == 3 * 3 + 2 and [len(x.split()) for x in lines[:9]] == [4, 4, 4, 8, 8, 8, 4, 4, 4]
