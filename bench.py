@@ -58,6 +58,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1: nccl (= RCCL over xGMI, the default) or gloo (rehearsal of the "
                          "multi-rank path on fewer GPUs than ranks; ranks then share devices and gather through host memory)")
+    ap.add_argument("--shard", default="grid", choices=["grid", "elements"],
+                    help="--gpus > 1: 'grid' (default) = strong scaling of ONE element's step, the grid prediction split over the "
+                         "ranks and all-gathered; 'elements' = weak scaling over the independent density-matrix elements, every "
+                         "rank fits and predicts its own element on the whole grid, no data-path collective (SURVEY.md §8e)")
     args = ap.parse_args()
 
     import torch
@@ -82,10 +86,12 @@ def main():
     N, G, kernel = WORKLOADS[args.workload]
     cplx = kernel == "complex"
     M = G * G
-    X, y, grid, theta = synthetic(N, G, 20240607 + 1, kernel)
-    # contiguous grid slice of this rank (padded to equal length so that all_gather_into_tensor applies)
-    per = (M + world - 1) // world
-    lo, hi = min(M, rank * per), min(M, (rank + 1) * per)
+    by_element = args.shard == "elements" and world > 1
+    X, y, grid, theta = synthetic(N, G, 20240607 + 1 + (rank if by_element else 0), kernel)
+    # contiguous grid slice of this rank (padded to equal length so that all_gather_into_tensor applies); a rank that owns a
+    # whole element predicts the whole grid
+    per = M if by_element else (M + world - 1) // world
+    lo, hi = (0, M) if by_element else (min(M, rank * per), min(M, (rank + 1) * per))
 
     stream = torch.cuda.current_stream()
     api = pkg.open_api(dev, stream=stream.cuda_stream)  # the library runs on torch's current stream
@@ -95,7 +101,7 @@ def main():
     dgrid = torch.from_numpy(grid[lo:hi].copy()).cuda()
     # rows: mean, variance, cut-off mean (real: 1 + 1 + 1, complex: 2 + 1 + 2 doubles per point)
     out_local = torch.zeros(5 if cplx else 3, per, dtype=torch.float64, device="cuda")
-    out_full = torch.zeros(world * out_local.shape[0], per, dtype=torch.float64, device="cuda") if world > 1 else None
+    out_full = torch.zeros(world * out_local.shape[0], per, dtype=torch.float64, device="cuda") if world > 1 and not by_element else None
     dp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))
     th = np.ascontiguousarray(theta)
     sc, ps = (c.ComplexFitScalars() if cplx else c.RealFitScalars()), c.PredictScalars()
@@ -116,7 +122,7 @@ def main():
         st = fn(api.ctx, h, dp(dgrid), hi - lo, c.IO_DEVICE, None, dp(o_mean), dp(o_var), dp(o_cut), C.byref(ps))
         if st != 0:
             raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
-        if world > 1:
+        if world > 1 and not by_element:
             if args.backend == "nccl":
                 dist.all_gather_into_tensor(out_full, out_local)  # RCCL, ordered on the same stream as the kernels
             else:
@@ -149,7 +155,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # sanity of the gathered grid: every rank must now hold all M points (checked once, outside the timed region)
-        full = out_full.view(world, out_local.shape[0], per).permute(1, 0, 2).reshape(out_local.shape[0], world * per)[:, :M]
+        full = out_local if by_element else out_full.view(world, out_local.shape[0], per).permute(1, 0, 2).reshape(out_local.shape[0], world * per)[:, :M]
         if not bool(torch.isfinite(full).all()):
             raise RuntimeError("gathered prediction contains non-finite values")
     ms_per_step = 1e3 * elapsed / args.steps
@@ -185,12 +191,13 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": False,
-        "scaling": "strong",
+        "scaling": "weak" if by_element else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: N={N} samples, {G}x{G} grid (M={M}), {kernel} SE kernel, fit(error+average) + grid predict(mean,var,cutoff)",
-                   "N": N, "M": M, "parallelism": f"grid-sharded x{world}, replicated fit, {'RCCL' if args.backend == 'nccl' else 'gloo (host)'} all-gather" if world > 1 else "single GPU"},
+                   "N": N, "M": M, "parallelism": (f"{world} independent density-matrix elements, one per GPU, no data-path collective" if by_element else
+                                   f"grid-sharded x{world}, replicated fit, {'RCCL' if args.backend == 'nccl' else 'gloo (host)'} all-gather") if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "kernel": "rownorm_kernel (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
                      "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
                      "traffic": traffic, "kernel_ms": round(pk_ms, 4), "launches_per_step": launches_per_step,
