@@ -112,14 +112,17 @@ const char* gple_ctx_last_error(const gple_ctx* ctx);
 
 /* ---- tracing --------------------------------------------------------------------------------------- */
 /* The reference only logs wall-clock seconds per output (output.cpp:246-248). With timing enabled the library
- * brackets its phases with HIP events on the context's stream; read them back after a call has completed. */
+ * brackets its phases with HIP events on the context's stream.  Timing never forces a synchronisation of its own: the
+ * intervals are collected at the library's next stream synchronisation (gple_ctx_synchronize, gple_ctx_get_timing, a
+ * scalar getter, a call with host outputs). */
 typedef enum gple_timer {
 	GPLE_TIMER_FIT = 0,            /* whole *_fit_create call (device side)                 */
 	GPLE_TIMER_PREDICT = 1,        /* whole *_predict call (device side)                    */
 	GPLE_TIMER_PREDICT_KERNEL = 2  /* the MFMA row-norm kernel of *_predict alone; count = its launches */
 } gple_timer;
 int gple_ctx_enable_timing(gple_ctx* ctx, int on);
-/* last: milliseconds of the most recent call; total / count: accumulated since enable (any may be NULL). */
+/* Synchronises the stream, then: last = milliseconds of the most recent interval; total / count = accumulated since
+ * enable (any may be NULL). */
 int gple_ctx_get_timing(gple_ctx* ctx, gple_timer which, double* last_ms, double* total_ms, long* count);
 
 /* ---- KernelBase (kernel.h:29-106, kernel.cpp:8-242) ---------------------------------------------- */
