@@ -24,8 +24,8 @@ namespace gple
 	// ys[i] = s * y[i*stride + offset] for i < N (0 for N <= i < Np), s = 10 / max_i |label_i|, written to *s_out.
 	// complex_abs != 0: |label| is the complex modulus of the (re,im) pair and both halves are produced:
 	// ys[0..Np) = s*re, ys[Np..2Np) = s*im.
-	hipError_t launch_prep_labels(hipStream_t s, const double* y, int stride, int complex_abs, int N, int Np, double* ys,
-		double* s_out);
+	hipError_t launch_prep_labels(hipStream_t s, const double* y, int stride, int complex_abs, int N, int Np, double* ys, double* s_out,
+		const double* X, double* Xt, int nscal);
 	// K_pad (n_total x n_total, ld) of the typed training set: n_total = Np (real) or 2*Np (complex, split at Np);
 	// points Xt (N interleaved); padded rows/cols get the identity.
 	hipError_t launch_gram_train(hipStream_t s, const double* Xt, int N, int Np, int n_total, SEParamSet ps, double* K, long ld);

@@ -50,11 +50,15 @@ namespace gple
 		}
 
 		// ------------------------------------------------------------------------------------------------------
+		// One launch prepares every input of a fit: the zero-padded copy of the training points, the cleared scalar block
+		// (s_out[0 .. nscal), info word included) and the rescaled, zero-padded labels with the rescale factor in s_out[0].
 		__global__ void __launch_bounds__(1024) prep_labels_kernel(const double* __restrict__ y, int stride, int complex_abs, int N,
-			int Np, double* __restrict__ ys, double* __restrict__ s_out)
+			int Np, double* __restrict__ ys, double* __restrict__ s_out, const double* __restrict__ X, double* __restrict__ Xt, int nscal)
 		{
 			__shared__ double red[16];
 			__shared__ double s_sh;
+			for (int i = threadIdx.x; i < 2 * Np; i += 1024) Xt[i] = i < 2 * N ? X[i] : 0.0;
+			for (int i = threadIdx.x; i < nscal; i += 1024) s_out[i] = 0.0;
 			double m = 0.0;
 			for (int i = threadIdx.x; i < N; i += 1024)
 			{
@@ -352,9 +356,10 @@ namespace gple
 		}
 	} // namespace
 
-	hipError_t launch_prep_labels(hipStream_t s, const double* y, int stride, int complex_abs, int N, int Np, double* ys, double* s_out)
+	hipError_t launch_prep_labels(hipStream_t s, const double* y, int stride, int complex_abs, int N, int Np, double* ys, double* s_out,
+		const double* X, double* Xt, int nscal)
 	{
-		hipLaunchKernelGGL(prep_labels_kernel, dim3(1), dim3(1024), 0, s, y, stride, complex_abs, N, Np, ys, s_out);
+		hipLaunchKernelGGL(prep_labels_kernel, dim3(1), dim3(1024), 0, s, y, stride, complex_abs, N, Np, ys, s_out, X, Xt, nscal);
 		return hipGetLastError();
 	}
 	hipError_t launch_gram_train(hipStream_t s, const double* Xt, int N, int Np, int n_total, SEParamSet ps, double* K, long ld)
