@@ -88,7 +88,7 @@ def _cplx(y):
 
 # every symbol include/gple.h declares (checked by tests/test_capi_symbols.py)
 GPLE_SYMBOLS = [
-    "ctx_create", "ctx_destroy", "ctx_synchronize", "status_string", "ctx_last_error", "ctx_enable_timing", "ctx_get_timing",
+    "ctx_create", "ctx_destroy", "ctx_synchronize", "ctx_trim", "status_string", "ctx_last_error", "ctx_enable_timing", "ctx_get_timing",
     "real_gram", "cutoff_factor",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
@@ -186,8 +186,15 @@ class Api:
             self.lib.gple_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
             self.lib.gple_ctx_destroy.argtypes = [C.c_void_p]
             self.lib.gple_ctx_synchronize.argtypes = [C.c_void_p]
+            self.lib.gple_ctx_trim.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
             self.lib.gple_status_string.argtypes, self.lib.gple_status_string.restype = [C.c_int], C.c_char_p
             self.lib.gple_ctx_last_error.argtypes, self.lib.gple_ctx_last_error.restype = [C.c_void_p], C.c_char_p
+
+    def trim(self):
+        """Free the pooled device buffers no live fit owns; returns the number of bytes released."""
+        n = C.c_size_t(0)
+        self._check(self.lib.gple_ctx_trim(self.ctx, C.byref(n)))
+        return n.value
 
     def _check(self, status):
         if status != GPLE_OK:

@@ -652,6 +652,29 @@ extern "C"
 		delete ctx;
 		return GPLE_OK;
 	}
+	int gple_ctx_trim(gple_ctx* ctx, size_t* bytes_freed)
+	{
+		if (!ctx) return GPLE_ERR_BAD_ARG;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		GPLE_HIP(ctx, hipStreamSynchronize(ctx->stream)); // nothing in flight may still be using an idle buffer
+		timer_collect(ctx);
+		size_t freed = 0;
+		{
+			std::lock_guard<std::mutex> pl(ctx->pool_mu);
+			std::vector<gple_ctx::PoolEntry> kept;
+			for (const gple_ctx::PoolEntry& e : ctx->pool)
+				if (e.used) kept.push_back(e);
+				else
+				{
+					(void)hipFree(e.p);
+					freed += e.bytes;
+				}
+			ctx->pool.swap(kept);
+		}
+		if (bytes_freed) *bytes_freed = freed;
+		return GPLE_OK;
+	}
 	int gple_ctx_synchronize(gple_ctx* ctx)
 	{
 		if (!ctx) return GPLE_ERR_BAD_ARG;

@@ -106,6 +106,10 @@ typedef enum gple_complex_array {
 int gple_ctx_create(int device, void* stream, gple_ctx** out);
 int gple_ctx_destroy(gple_ctx* ctx);
 int gple_ctx_synchronize(gple_ctx* ctx);
+/* The context keeps every device buffer it ever needed in a grow-only pool (no hipMalloc on the steady-state path; a single
+ * large predict can leave up to 4 GiB of K* scratch behind). This synchronises the stream and frees the buffers that no live
+ * fit owns; *bytes_freed (nullable) receives the amount. */
+int gple_ctx_trim(gple_ctx* ctx, size_t* bytes_freed);
 const char* gple_status_string(int status);
 /* Last HIP error text seen by this context (empty string when none). */
 const char* gple_ctx_last_error(const gple_ctx* ctx);

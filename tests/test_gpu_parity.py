@@ -359,3 +359,16 @@ def test_small_m_and_streaming_predict_paths_agree(gpu, monkeypatch):
         out[force] = gpu.complex_predict(cfit, Xs[:333])
     assert np.array_equal(out["0"]["prediction"], out["1"]["prediction"])
     assert np.abs(out["0"]["variance"] - out["1"]["variance"]).max() <= 1e-11 * 4.0
+
+
+def test_ctx_trim_releases_idle_buffers_only(gpu):
+    """the grow-only pool can be emptied between phases; live fits keep their buffers and keep working"""
+    X, y, Xs = parity.synthetic_real(200, 4000, 55)
+    fit = gpu.real_fit([1.0, 0.7086, 0.7056, 1e-2], X, y, 3)
+    before = gpu.real_predict(fit, Xs)
+    freed = gpu.trim()
+    assert freed > 4000 * 256 * 8  # at least the K* scratch of that predict
+    assert gpu.trim() == 0          # nothing idle is left
+    after = gpu.real_predict(fit, Xs)
+    assert np.array_equal(before["prediction"], after["prediction"]) and np.array_equal(before["variance"], after["variance"])
+    assert fit.scalars["info"] == 0
