@@ -92,7 +92,7 @@ GPLE_SYMBOLS = [
     "real_gram", "cutoff_factor",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
-    "complex_predict", "loose_function", "nlml", "nlml_predict",
+    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "nlml", "nlml_predict",
 ]
 
 
@@ -142,6 +142,34 @@ class _Fit:
         return arr.T.copy() if which in (C_KERNEL, C_PSEUDO, C_UPPER_LEFT, C_LOWER_LEFT) else arr
 
 
+class _Objective:
+    """Owns one gple_objective handle (training and extra set resident on the device)."""
+
+    def __init__(self, api, X, y, Xe, ye):
+        self.api, self.handle = api, C.c_void_p()
+        api._check(api.lib.gple_objective_create(api.ctx, _ptr(X), _ptr(y.view(np.float64)), len(X), _ptr(Xe), _ptr(ye.view(np.float64)),
+                                                 len(Xe), C.byref(self.handle)))
+        api._fits.add(self)  # released with the context, like the fits
+
+    def __call__(self, x, want_grad=True):
+        x = _f64(x)
+        val = C.c_double()
+        grad = np.empty(len(x)) if want_grad else None
+        self.api._check(self.api.lib.gple_objective_eval(self.handle, _ptr(x), len(x), C.cast(C.byref(val), _dp), _ptr(grad)))
+        return val.value, grad
+
+    def release(self):
+        if self.handle:
+            self.api.lib.gple_objective_release(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class Api:
     def __init__(self, lib, prefix, with_ctx, device=0, stream=None):
         self.lib, self.prefix, self.with_ctx = lib, prefix, with_ctx
@@ -183,6 +211,9 @@ class Api:
             for kind, st in (("real", RealFitScalars), ("complex", ComplexFitScalars)):
                 f = self._fn(f"{kind}_fit_get_scalars")
                 f.argtypes, f.restype = [vp, C.POINTER(st)], C.c_int
+            self.lib.gple_objective_create.argtypes = [vp, _dp, _dp, sz, _dp, _dp, sz, C.POINTER(vp)]
+            self.lib.gple_objective_eval.argtypes = [vp, _dp, sz, _dp, _dp]
+            self.lib.gple_objective_release.argtypes = [vp]
             self.lib.gple_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
             self.lib.gple_ctx_destroy.argtypes = [C.c_void_p]
             self.lib.gple_ctx_synchronize.argtypes = [C.c_void_p]
@@ -317,6 +348,15 @@ class Api:
         self._check(self._fn("loose_function")(*self._c(), _ptr(x), len(x), _ptr(X), _ptr(yy), len(X), _ptr(Xe), _ptr(ye),
                                                len(Xe), C.cast(C.byref(val), _dp), _ptr(grad)))
         return val.value, grad
+
+    def objective(self, X, y, X_extra, y_extra):
+        """loose_function with its data resident on the device: returns f(x, want_grad=True) -> (value, grad or None).  The
+        oracle has no device: there the closure simply keeps the arrays."""
+        X, Xe = _points(X), _points(X_extra)
+        yy, ye = _cplx(y), _cplx(y_extra)
+        if not self.with_ctx:
+            return lambda x, want_grad=True: self.loose_function(x, X, yy, Xe, ye, want_grad=want_grad)
+        return _Objective(self, X, yy, Xe, ye)
 
     def nlml(self, x, X, y, want_grad=True):
         x, X, y = _f64(x), _points(X), _f64(y)

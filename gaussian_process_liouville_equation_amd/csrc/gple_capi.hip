@@ -1297,11 +1297,11 @@ extern "C"
 		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
 	}
 
-	// loose_function (opt.cpp:441-482)
-	int gple_loose_function(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N, const double* X_extra,
-		const double* y_extra, size_t M_extra, double* value, double* grad)
+	// loose_function (opt.cpp:441-482).  io = 0: host pointers; io = GPLE_IO_DEVICE: everything but x / value / grad is resident
+	// (lab = real parts of y_extra, the label vector of the real kernel's PredictiveKernel, opt.cpp:451)
+	static int loose_eval(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N, const double* X_extra,
+		const double* y_extra, const double* lab, size_t M_extra, unsigned io, double* value, double* grad)
 	{
-		if (!ctx || !x || !X || !y || !value || (n != 4 && n != 8) || (M_extra && (!X_extra || !y_extra))) return GPLE_ERR_BAD_ARG;
 		const unsigned flags = GPLE_CALC_ERROR | (grad ? GPLE_CALC_DERIVATIVE : 0u);
 		gple_predict_scalars ps;
 		double result = 0.0;
@@ -1309,10 +1309,8 @@ extern "C"
 		{
 			gple_real_fit_scalars sc;
 			gple_real_fit* fit = nullptr;
-			GPLE_TRY(gple_real_fit_create(ctx, x, X, y, 1, N, flags, &sc, &fit));
-			std::vector<double> lab(M_extra);
-			for (size_t i = 0; i < M_extra; ++i) lab[i] = y_extra[2 * i]; // ExtraTrainingLabel.real(), opt.cpp:451
-			const int st = gple_real_predict(ctx, fit, X_extra, M_extra, flags & GPLE_CALC_DERIVATIVE, lab.data(), nullptr, nullptr, nullptr, &ps);
+			GPLE_TRY(gple_real_fit_create(ctx, x, X, y, 1, N, flags | io, &sc, &fit));
+			const int st = gple_real_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io, lab, nullptr, nullptr, nullptr, &ps);
 			gple_real_fit_release(fit);
 			GPLE_TRY(st);
 			result = sc.error + (M_extra ? ps.error : 0.0);
@@ -1323,8 +1321,8 @@ extern "C"
 		{
 			gple_complex_fit_scalars sc;
 			gple_complex_fit* fit = nullptr;
-			GPLE_TRY(gple_complex_fit_create(ctx, x, X, y, N, flags, &sc, &fit));
-			const int st = gple_complex_predict(ctx, fit, X_extra, M_extra, flags & GPLE_CALC_DERIVATIVE, y_extra, nullptr, nullptr, nullptr, &ps);
+			GPLE_TRY(gple_complex_fit_create(ctx, x, X, y, N, flags | io, &sc, &fit));
+			const int st = gple_complex_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io, y_extra, nullptr, nullptr, nullptr, &ps);
 			gple_complex_fit_release(fit);
 			GPLE_TRY(st);
 			result = sc.error + (M_extra ? ps.error : 0.0);
@@ -1339,6 +1337,65 @@ extern "C"
 		if (grad)
 			for (size_t i = 0; i < n; ++i) make_normal(grad[i]);
 		*value = result;
+		return GPLE_OK;
+	}
+	int gple_loose_function(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N, const double* X_extra,
+		const double* y_extra, size_t M_extra, double* value, double* grad)
+	{
+		if (!ctx || !x || !X || !y || !value || (n != 4 && n != 8) || (M_extra && (!X_extra || !y_extra))) return GPLE_ERR_BAD_ARG;
+		std::vector<double> lab(M_extra);
+		for (size_t i = 0; i < M_extra; ++i) lab[i] = y_extra[2 * i];
+		return loose_eval(ctx, x, n, X, y, N, X_extra, y_extra, lab.data(), M_extra, 0u, value, grad);
+	}
+
+	// ---- the objective with its data resident (ElementTrainingParameters of opt.cpp:16) ------------------------------------
+	struct gple_objective
+	{
+		gple_ctx* ctx = nullptr;
+		size_t N = 0, M = 0;
+		double *X = nullptr, *y = nullptr, *Xe = nullptr, *ye = nullptr, *lab = nullptr;
+	};
+	int gple_objective_create(gple_ctx* ctx, const double* X, const double* y, size_t N, const double* X_extra, const double* y_extra,
+		size_t M_extra, gple_objective** out)
+	{
+		if (!ctx || !X || !y || !out || N == 0 || (M_extra && (!X_extra || !y_extra))) return GPLE_ERR_BAD_ARG;
+		*out = nullptr;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		gple_objective* o = new (std::nothrow) gple_objective;
+		if (!o) return GPLE_ERR_ALLOC;
+		o->ctx = ctx, o->N = N, o->M = M_extra;
+		hipStream_t st = ctx->stream;
+		hipError_t e = hipSuccess;
+		auto up = [&](double*& dst, const double* src, size_t n) {
+			if (e != hipSuccess || n == 0) return;
+			dst = ctx->acquire(n * 8, &e);
+			if (e == hipSuccess) e = hipMemcpyAsync(dst, src, n * 8, hipMemcpyHostToDevice, st);
+		};
+		std::vector<double> lab(M_extra);
+		for (size_t i = 0; i < M_extra; ++i) lab[i] = y_extra[2 * i];
+		up(o->X, X, 2 * N), up(o->y, y, 2 * N), up(o->Xe, X_extra, 2 * M_extra), up(o->ye, y_extra, 2 * M_extra), up(o->lab, lab.data(), M_extra);
+		if (e == hipSuccess) e = hipStreamSynchronize(st); // the host arrays may go away once this returns
+		if (e != hipSuccess)
+		{
+			for (double* p : {o->X, o->y, o->Xe, o->ye, o->lab}) ctx->give_back(p);
+			delete o;
+			return record_hip_error(ctx, e, "objective upload", __LINE__);
+		}
+		*out = o;
+		return GPLE_OK;
+	}
+	int gple_objective_eval(gple_objective* o, const double* x, size_t n, double* value, double* grad)
+	{
+		if (!o || !x || !value || (n != 4 && n != 8)) return GPLE_ERR_BAD_ARG;
+		return loose_eval(o->ctx, x, n, o->X, o->y, o->N, o->Xe, o->ye, o->lab, o->M, GPLE_IO_DEVICE, value, grad);
+	}
+	int gple_objective_release(gple_objective* o)
+	{
+		if (!o) return GPLE_OK;
+		(void)hipStreamSynchronize(o->ctx->stream);
+		for (double* p : {o->X, o->y, o->Xe, o->ye, o->lab}) o->ctx->give_back(p);
+		delete o;
 		return GPLE_OK;
 	}
 

@@ -419,13 +419,29 @@ def local_gradient_to_global(param, grad):  # opt.cpp:155-192: d/d ln x = x d/dx
 
 def loose_function(x, grad, params, api=None):
     """opt.cpp:441-482.  grad: a list of len(x) to be filled in place, or an empty list for 'no gradient' (the NLopt
-    convention).  params = (TrainingSet, ExtraTrainingSet), each (feature, label)."""
+    convention).  params = (TrainingSet, ExtraTrainingSet), each (feature, label); an optional third entry is a resident
+    objective (`api.objective(...)`: the same two sets already on the device) that is then evaluated instead."""
     api = api or default_api()
-    (X, y), (Xe, ye) = params
-    value, g = api.loose_function(x, X, np.asarray(y, dtype=complex), Xe, np.asarray(ye, dtype=complex), want_grad=len(grad) > 0)
+    if len(params) > 2 and params[2] is not None:
+        value, g = params[2](x, want_grad=len(grad) > 0)
+    else:
+        (X, y), (Xe, ye) = params[0], params[1]
+        value, g = api.loose_function(x, X, np.asarray(y, dtype=complex), Xe, np.asarray(ye, dtype=complex), want_grad=len(grad) > 0)
     if len(grad) > 0:
         grad[:] = list(g)
     return value
+
+
+def resident_objective(cache, api, element, TrainingSets, ExtraTrainingSets):
+    """One resident objective per (context, element) for the lifetime of `cache` (a dict the caller owns, e.g. one per
+    Optimization.optimize call): NLopt's `void* params` made device-resident.  None when no cache is given."""
+    if cache is None:
+        return None
+    key = (id(api), element)
+    if key not in cache:
+        (X, y), (Xe, ye) = TrainingSets[element], ExtraTrainingSets[element]
+        cache[key] = api.objective(X, y, Xe, ye)
+    return cache[key]
 
 
 def loose_function_global_wrapper(x, grad, params, api=None):  # opt.cpp:489-497
@@ -438,13 +454,15 @@ def loose_function_global_wrapper(x, grad, params, api=None):  # opt.cpp:489-497
 
 def diagonal_loose(x, grad, params, api=None, num_pes=None):
     """opt.cpp:594-617: sum of loose_function over the diagonal elements on parameter slices of 4."""
-    TrainingSets, ExtraTrainingSets = params
+    TrainingSets, ExtraTrainingSets = params[0], params[1]
+    cache = params[2] if len(params) > 2 else None
     n = num_pes or NumPES
     active = [i for i in range(n) if len(TrainingSets[(i, i)][0]) != 0]
 
     def one(one_api, i):
         g = [0.0] * REAL_NPARAM if len(grad) > 0 else []
-        v = loose_function(x[i * REAL_NPARAM:(i + 1) * REAL_NPARAM], g, (TrainingSets[(i, i)], ExtraTrainingSets[(i, i)]), api=one_api)
+        obj = resident_objective(cache, one_api or default_api(), (i, i), TrainingSets, ExtraTrainingSets)
+        v = loose_function(x[i * REAL_NPARAM:(i + 1) * REAL_NPARAM], g, (TrainingSets[(i, i)], ExtraTrainingSets[(i, i)], obj), api=one_api)
         return v, g
 
     results = api.map(one, active) if isinstance(api, ApiPool) else [one(api, i) for i in active]
@@ -478,15 +496,18 @@ def construct_combined_parameters(x, num_pes=None):  # opt.cpp:825-837
 
 def full_loose(x, grad, params, api=None, num_pes=None):
     """opt.cpp:844-870"""
-    TrainingSets, ExtraTrainingSets = params
+    TrainingSets, ExtraTrainingSets = params[0], params[1]
+    cache = params[2] if len(params) > 2 else None
     allp = construct_all_parameters(x, num_pes)
     order = element_order(num_pes)
 
     def one(one_api, e):
         n = REAL_NPARAM if e[0] == e[1] else COMPLEX_NPARAM
         g = [0.0] * n if len(grad) > 0 else []
-        v = loose_function(allp[e], g, (TrainingSets[e], ExtraTrainingSets[e]), api=one_api) if len(TrainingSets[e][0]) != 0 else 0.0
-        return v, g
+        if len(TrainingSets[e][0]) == 0:
+            return 0.0, g
+        obj = resident_objective(cache, one_api or default_api(), e, TrainingSets, ExtraTrainingSets)
+        return loose_function(allp[e], g, (TrainingSets[e], ExtraTrainingSets[e], obj), api=one_api), g
 
     results = api.map(one, order) if isinstance(api, ApiPool) else [one(api, e) for e in order]
     err, grads = 0.0, {}

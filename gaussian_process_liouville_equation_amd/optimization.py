@@ -224,7 +224,8 @@ class Optimization:
         def search(one_api, e):
             if len(TrainingSets[e][0]) == 0:
                 return params[e], 0.0, 0
-            etp = (TrainingSets[e], ExtraTrainingSets[e])
+            # the two sets go to the device once per optimize() call; the hundreds of evaluations move only the parameters
+            etp = (TrainingSets[e], ExtraTrainingSets[e], K.resident_objective(self._objectives, one_api, e, TrainingSets, ExtraTrainingSets))
             lb, ub = self._bounds[e]
             try:
                 if is_global:
@@ -251,7 +252,7 @@ class Optimization:
         n = self.num_pes
         x0 = [v for i in range(n) for v in params[(i, i)]]
         m = 3 if Purity > 0 else 2
-        obj = lambda x, g: K.diagonal_loose(x, g, (TrainingSets, ExtraTrainingSets), api=self.api, num_pes=n)
+        obj = lambda x, g: K.diagonal_loose(x, g, (TrainingSets, ExtraTrainingSets, self._objectives), api=self.api, num_pes=n)
         con = lambda x, want: K.diagonal_constraints(m, x, want, (TrainingSets, Energies, self.TotalEnergy, Purity), api=self.api, num_pes=n)
         x, err, steps = _auglag_eq(obj, con, m, x0, self._stack(0, True), self._stack(1, True))
         for i in range(n):
@@ -262,7 +263,7 @@ class Optimization:
         """opt.cpp:1045-1118"""
         n = self.num_pes
         x0 = K.construct_combined_parameters(params, n)
-        obj = lambda x, g: K.full_loose(x, g, (TrainingSets, ExtraTrainingSets), api=self.api, num_pes=n)
+        obj = lambda x, g: K.full_loose(x, g, (TrainingSets, ExtraTrainingSets, self._objectives), api=self.api, num_pes=n)
         con = lambda x, want: K.full_constraints(x, want, (TrainingSets, Energies, self.TotalEnergy, self.Purity), api=self.api, num_pes=n)
         x, err, steps = _auglag_eq(obj, con, 3, x0, self._stack(0, False), self._stack(1, False))
         params.update(K.construct_all_parameters(x, n))
@@ -278,6 +279,10 @@ class Optimization:
         """opt.cpp:1019-1392"""
         TrainingSets = K.construct_training_sets(density, self.num_pes)
         ExtraTrainingSets = K.construct_training_sets(extra_points, self.num_pes)
+        for o in getattr(self, "_objectives", {}).values():  # the previous step's resident sets
+            if hasattr(o, "release"):
+                o.release()
+        self._objectives = {}
         n = self.num_pes
         Energies = [0.0 if len(TrainingSets[(i, i)][0]) == 0 else
                     calculate_total_energy_average_one_surface(TrainingSets[(i, i)], self.mass, i, self.potential) for i in range(n)]

@@ -187,6 +187,16 @@ int gple_complex_predict(gple_ctx* ctx, const gple_complex_fit* fit, const doubl
 int gple_loose_function(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N,
 	const double* X_extra, const double* y_extra, size_t M_extra, double* value, double* grad);
 
+/* The same objective with its data resident: ElementTrainingParameters (opt.cpp:16), i.e. the training set and the extra set
+ * an NLopt optimiser carries in its `void* params` across hundreds of evaluations, are uploaded once; an evaluation then moves
+ * the parameter vector in and the value (+ gradient) out.  X: 2N, y: N (re,im) pairs, extra set likewise (M_extra may be 0). */
+typedef struct gple_objective gple_objective;
+int gple_objective_create(gple_ctx* ctx, const double* X, const double* y, size_t N, const double* X_extra, const double* y_extra,
+	size_t M_extra, gple_objective** out);
+/* loose_function(x, grad, params): n = 4 (real element) or 8 (complex element); grad may be NULL. */
+int gple_objective_eval(gple_objective* objective, const double* x, size_t n, double* value, double* grad);
+int gple_objective_release(gple_objective* objective);
+
 /* ---- negative_log_marginal_likelihood / predict (test/gpr.cpp:499-532, 654-706) -------------------- */
 /* Kernel = w_d^2 * Diag + w_g^2 * GaussianARD(weights), x = (w_d, w_g, a_x, a_p) with `a` the diagonal ARD
  * weights = inverse lengths (NOCROSS build, test/gpr.cpp:99,323-326). value = y^T K^-1 y / 2 + sum log L_ii;

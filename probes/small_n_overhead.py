@@ -21,4 +21,10 @@ for N in (300, 500, 1024):
         _, ft, fc = api.timing(0); _, pt, pc = api.timing(1)
         print(f"N={N} grad={g}: wall {wall:.3f} ms, fit on device {ft / fc:.3f} ms, predict on device {pt / pc:.3f} ms, host/other {wall - ft / fc - pt / pc:.3f} ms", flush=True)
         api.enable_timing(False)
+        obj = api.objective(X, yc, Xs, ye)
+        for _ in range(5): obj(th, want_grad=g)
+        t = time.perf_counter()
+        for _ in range(n): obj(th, want_grad=g)
+        print(f"    resident objective: wall {(time.perf_counter() - t) / n * 1e3:.3f} ms", flush=True)
+        obj.release()
 api.close()

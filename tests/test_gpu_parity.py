@@ -372,3 +372,23 @@ def test_ctx_trim_releases_idle_buffers_only(gpu):
     after = gpu.real_predict(fit, Xs)
     assert np.array_equal(before["prediction"], after["prediction"]) and np.array_equal(before["variance"], after["variance"])
     assert fit.scalars["info"] == 0
+
+
+def test_resident_objective_equals_loose_function(gpu):
+    """gple_objective_*: the data uploaded once; every evaluation equals gple_loose_function on host arrays bit for bit"""
+    X, y, Xs = parity.synthetic_real(333, 120, 17)
+    ye = (0.01 + 0.0 * Xs[:, 0]).astype(complex)
+    yc = 0.5 * y * np.exp(0.5j * (X[:, 0] + 10.0))
+    yec = 0.5 * ye * np.exp(0.5j * (Xs[:, 0] + 10.0))
+    for theta, yy, yee in (([1.0, 0.7086, 0.7056, 1e-2], y.astype(complex), ye), ([1.0, 1.0, 0.7086, 0.7056, 1.2, 0.8, 0.6, 1e-2], yc, yec)):
+        obj = gpu.objective(X, yy, Xs, yee)
+        for scale in (1.0, 0.9, 1.1):
+            th = [theta[0]] + [t * scale for t in theta[1:-1]] + [theta[-1]]
+            for g in (True, False):
+                v1, g1 = obj(th, want_grad=g)
+                v2, g2 = gpu.loose_function(th, X, yy, Xs, yee, want_grad=g)
+                assert v1 == v2 and (g1 is None) == (g2 is None) and (g1 is None or np.array_equal(g1, g2))
+        obj.release()
+    empty = gpu.objective(X, y.astype(complex), np.zeros((0, 2)), np.zeros(0, complex))  # no extra set
+    v, _ = empty([1.0, 0.7086, 0.7056, 1e-2], want_grad=False)
+    assert v == gpu.loose_function([1.0, 0.7086, 0.7056, 1e-2], X, y.astype(complex), np.zeros((0, 2)), np.zeros(0, complex), want_grad=False)[0]
