@@ -40,7 +40,6 @@ namespace gple
 		constexpr int BM = 128, BN = 256, BK = 16;
 		constexpr int AS = BM + 16; // LDS row stride of the K* slab [k][m]
 		constexpr int BS = BN + 16; // LDS row stride of the T tile [k][n]
-		constexpr int A_SLAB = BK * AS, B_SLAB = BK * BS;
 		constexpr int NTHREADS = 512;
 		constexpr int GEN_KSPLIT_MIN = 8, GEN_KSPLIT_MAX = 64; // k-ranges per row in the generation kernel (partial means)
 		// few test rows: split k further so that the generation still fills the chip (>= ~512 workgroups of 128 rows)
