@@ -37,8 +37,7 @@ namespace gple
 
 	namespace
 	{
-		constexpr int BM = 128, BN = 256, BK = 16;
-		constexpr int AS = BM + 16; // LDS row stride of the K* slab [k][m]
+		constexpr int BM = 128, BN = 256;
 		constexpr int BS = BN + 16; // LDS row stride of the T tile [k][n]
 		constexpr int NTHREADS = 512;
 		constexpr int GEN_KSPLIT_MIN = 8, GEN_KSPLIT_MAX = 64; // k-ranges per row in the generation kernel (partial means)
