@@ -948,6 +948,16 @@ extern "C"
 	}
 
 	// ---- PredictiveKernel --------------------------------------------------------------------------------------
+	// internal flag of predict_common (never part of the ABI's flag space): enqueue everything, including the D2H copies of
+	// the error scalars, but leave the synchronisation and the scalar read-out to the caller
+	constexpr unsigned PREDICT_NO_SYNC = 0x10000u;
+	static void predict_scalars_from_host(gple_ctx* ctx, bool has_labels, bool want_deriv, bool cplx, gple_predict_scalars* scalars)
+	{
+		if (!scalars) return;
+		if (has_labels) scalars->error = ctx->host_scalars[HS_PRED_ERR];
+		if (want_deriv)
+			for (int ip = 0; ip < (cplx ? 8 : 4); ++ip) scalars->error_derivative[ip] = ctx->host_scalars[HS_PRED_DERIV + ip];
+	}
 	static int predict_common(gple_ctx* ctx, const FitCommon* f, const double* Xs, size_t M, unsigned flags, const double* labels,
 		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars)
 	{
@@ -1056,14 +1066,13 @@ extern "C"
 		timer_stop(ctx, GPLE_TIMER_PREDICT);
 		// host outputs (and the error scalar) need the stream drained; device-pointer calls without labels stay asynchronous
 		// (pooled scratch is only ever reused by later work on this same stream, which the stream orders)
+		if (flags & PREDICT_NO_SYNC) return GPLE_OK; // internal: the caller drains the stream and reads the scalars itself
 		if (!dev || labels)
 		{
 			GPLE_HIP(ctx, hipStreamSynchronize(st));
 			timer_collect(ctx);
 		}
-		if (labels && scalars) scalars->error = ctx->host_scalars[HS_PRED_ERR];
-		if (want_deriv && scalars)
-			for (int ip = 0; ip < (cplx ? 8 : 4); ++ip) scalars->error_derivative[ip] = ctx->host_scalars[HS_PRED_DERIV + ip];
+		predict_scalars_from_host(ctx, labels != nullptr, want_deriv, cplx, scalars);
 		return GPLE_OK;
 	}
 
@@ -1305,14 +1314,19 @@ extern "C"
 		const unsigned flags = GPLE_CALC_ERROR | (grad ? GPLE_CALC_DERIVATIVE : 0u);
 		gple_predict_scalars ps;
 		double result = 0.0;
+		// The fit's scalars are deferred and the predict leaves its synchronisation to us: the whole evaluation is enqueued in one
+		// go and the stream is drained once (a synchronisation between fit and predict would idle the GPU for the host's turn)
+		const bool want_deriv = (flags & GPLE_CALC_DERIVATIVE) && M_extra;
 		if (n == 4)
 		{
 			gple_real_fit_scalars sc;
 			gple_real_fit* fit = nullptr;
-			GPLE_TRY(gple_real_fit_create(ctx, x, X, y, 1, N, flags | io, &sc, &fit));
-			const int st = gple_real_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io, lab, nullptr, nullptr, nullptr, &ps);
+			GPLE_TRY(gple_real_fit_create(ctx, x, X, y, 1, N, flags | io, nullptr, &fit));
+			int st = gple_real_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io | PREDICT_NO_SYNC, lab, nullptr, nullptr, nullptr, &ps);
+			if (st == GPLE_OK) st = gple_real_fit_get_scalars(fit, &sc); // drains the stream
 			gple_real_fit_release(fit);
 			GPLE_TRY(st);
+			if (M_extra) predict_scalars_from_host(ctx, true, want_deriv, false, &ps);
 			result = sc.error + (M_extra ? ps.error : 0.0);
 			if (grad)
 				for (int i = 0; i < 4; ++i) grad[i] = sc.error_derivative[i] + (M_extra ? ps.error_derivative[i] : 0.0);
@@ -1321,10 +1335,12 @@ extern "C"
 		{
 			gple_complex_fit_scalars sc;
 			gple_complex_fit* fit = nullptr;
-			GPLE_TRY(gple_complex_fit_create(ctx, x, X, y, N, flags | io, &sc, &fit));
-			const int st = gple_complex_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io, y_extra, nullptr, nullptr, nullptr, &ps);
+			GPLE_TRY(gple_complex_fit_create(ctx, x, X, y, N, flags | io, nullptr, &fit));
+			int st = gple_complex_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io | PREDICT_NO_SYNC, y_extra, nullptr, nullptr, nullptr, &ps);
+			if (st == GPLE_OK) st = gple_complex_fit_get_scalars(fit, &sc);
 			gple_complex_fit_release(fit);
 			GPLE_TRY(st);
+			if (M_extra) predict_scalars_from_host(ctx, true, want_deriv, true, &ps);
 			result = sc.error + (M_extra ? ps.error : 0.0);
 			if (grad)
 				for (int i = 0; i < 8; ++i) grad[i] = sc.error_derivative[i] + (M_extra ? ps.error_derivative[i] : 0.0);
