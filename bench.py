@@ -4,15 +4,19 @@
 One step = what the reference does per output tick for one density-matrix element:
   TrainingKernel(theta, set, error=1, average=1, derivative=0)      (predict.cpp:390-393)
 + PredictiveKernel(grid, kernel, false): mean, variance, cut-off    (output.cpp:204-207)
-Workload C2 (BASELINE.json configs[1]): N = 1024 samples, 256 x 256 grid, real SE kernel, fp64, synthetic inputs of
-SURVEY.md §8(d) (seed 20240607 + 1).  Inputs are resident in HBM before the timed region.
+Default workload C4r = the north-star size of BASELINE.json (N = 4096 samples, 512 x 512 grid, real SE kernel, fp64),
+synthetic inputs of SURVEY.md §8(d) (seed 20240607 + 1).  Inputs are resident in HBM before the timed region.
 N > 1 GPUs: strong scaling of the same step — every rank fits (replicated, no broadcast needed) and predicts its
-contiguous slice of the grid; the slices are all-gathered over RCCL (the north-star partition).
+contiguous slice of the grid (parallel.GridShardedStep); the slices are all-gathered over RCCL (the north-star partition).
+`--workload C4opt` is the optimiser's inner loop instead (opt.cpp:441-482): one step = loose_function value + gradient of
+the three density-matrix elements of a 2-state system (2 real + 1 complex GP, N = 4096, 5N extra points each).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -22,14 +26,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {  # name: (N, G, kernel)
-    "C1": (256, 128, "real"),
-    "C2": (1024, 256, "real"),      # BASELINE.json configs[1]: the default
+    "C1": (256, 128, "real"),       # BASELINE.json configs[0]: the reference's own CPU-runnable case
+    "C2": (1024, 256, "real"),      # configs[1]
     "C3": (2048, 256, "complex"),   # configs[2]: off-diagonal density-matrix element
-    "C4r": (4096, 512, "real"),     # one real element of C4 = the north-star target size
+    "C4r": (4096, 512, "real"),     # one real element of configs[3] = the north-star target size: the default
     "C4c": (4096, 512, "complex"),  # the complex element of C4
     "C5r": (8192, 1024, "real"),    # one real element of C5
+    "C4opt": (4096, 0, "opt"),      # the opt.cpp loop of configs[3]: 2 real + 1 complex objective evaluations with gradient
 }
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak; measured 78.4 with v_mfma_f64_16x16x4_f64
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def synthetic(N, G, seed, kernel="real"):
@@ -37,6 +43,7 @@ def synthetic(N, G, seed, kernel="real"):
     x0, p0, sx, sp = -10.0, 14.112, 0.7086, 0.7056
     X = rng.normal([x0, p0], [sx, sp], size=(N, 2))
     y = np.exp(-0.5 * (((X[:, 0] - x0) / sx) ** 2 + ((X[:, 1] - p0) / sp) ** 2)) / (2 * np.pi * sx * sp)
+    G = max(G, 1)
     dx = 40.0 / G
     xs = -20.0 + dx * np.arange(G)
     ps = (p0 - np.pi / (2 * dx)) + (np.pi / dx / G) * np.arange(G)
@@ -48,12 +55,96 @@ def synthetic(N, G, seed, kernel="real"):
     return X, y, grid, np.array([1.0, sx, sp, 1e-2])
 
 
+def extra_points(X, seed, kernel):
+    """validation set of the opt loop (mc.cpp:59-94): 5N points r_{i mod N} + N(0, std(r)^2), exact labels"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x0, p0, sx, sp = -10.0, 14.112, 0.7086, 0.7056
+    N = len(X)
+    Xe = X[np.arange(5 * N) % N] + rng.normal(0.0, X.std(axis=0), size=(5 * N, 2))
+    ye = np.exp(-0.5 * (((Xe[:, 0] - x0) / sx) ** 2 + ((Xe[:, 1] - p0) / sp) ** 2)) / (2 * np.pi * sx * sp)
+    if kernel == "complex":
+        ye = 0.5 * ye * np.exp(0.5j * (Xe[:, 0] - x0))
+    return Xe, ye.astype(complex)
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except (OSError, subprocess.SubprocessError):
+        return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def traffic_for(workload, world):
+    """HBM bytes of one rownorm_kernel launch: PMC counters cannot be read from inside the run, so the value committed under
+    profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950 guide prescribes)
+    is reported when it was taken on this workload at this GPU count; `source` says which commit's kernels it was taken on."""
+    try:
+        tj = json.load(open(TRAFFIC_FILE))
+        e = tj.get(workload)
+        if e and world == 1:
+            return e["hbm_bytes_per_launch"], {"file": os.path.relpath(TRAFFIC_FILE, ROOT), "git": e.get("git"), "kernel_src_sha16": e.get("kernel_src_sha16")}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+def cpu_baseline(workload, N, G, kernel, X, y, grid, theta, runs=3):
+    """The oracle (CPU restatement of the reference's algorithm: materialised K*, pivoted LDLT, explicit inverse, per-row
+    row W row^T variance loop) on this box's host cores, bounded sample: full fit + a slice of the grid extrapolated linearly
+    in M (rows are independent), median of `runs`; plus the same slice on ONE core."""
+    from oracle import binding
+    ora = binding.load()
+    M = len(grid)
+    cplx = kernel == "complex"
+    fit_fn = (lambda: ora.complex_fit(theta, X, y, 3)) if cplx else (lambda: ora.real_fit(theta, X, y, 3))
+    pred_fn = ora.complex_predict if cplx else ora.real_predict
+    # slice sized for ~3 s per run at this N on 16 threads (2 M N^2 flops real, 32 M N^2 complex; the port sustains ~70 GFLOP/s)
+    m_s = int(min(M, max(256, 2e11 / ((16.0 if cplx else 1.0) * 2.0 * N * N))))
+    tfs, tps, fo = [], [], None
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fo = fit_fn()
+        tfs.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        pred_fn(fo, grid[:m_s])
+        tps.append((time.perf_counter() - t0) * (M / m_s))
+    tf, tp = statistics.median(tfs), statistics.median(tps)
+    # one core: a smaller slice of the predict, the fit only while it stays within seconds
+    ora.lib.oracle_set_num_threads(1)
+    m_1 = max(64, m_s // 16)
+    t0 = time.perf_counter()
+    pred_fn(fo, grid[:m_1])
+    tp1 = (time.perf_counter() - t0) * (M / m_1)
+    tf1 = None
+    if N <= (1024 if cplx else 2048):
+        t0 = time.perf_counter()
+        fit_fn()
+        tf1 = time.perf_counter() - t0
+    ora.lib.oracle_set_num_threads(ora.num_threads)
+    return {"value": round(1e3 * (tf + tp), 1), "unit": "ms/step", "cores": ora.num_threads, "kind": "port",
+            "cpu_model": cpu_model(), "runs": runs, "fit_ms_median": round(1e3 * tf, 1), "predict_ms_median_scaled": round(1e3 * tp, 1),
+            "one_core_ms": {"predict_scaled": round(1e3 * tp1, 1), "fit": None if tf1 is None else round(1e3 * tf1, 1),
+                            "sample": f"predict on {m_1} of {M} grid points scaled to M" + ("" if tf1 is not None else "; fit not timed on one core at this N (minutes)")},
+            "sample": f"oracle (CPU restatement of the reference's algorithm, OpenMP, {ora.num_threads} threads), median of {runs}: full fit N={N} "
+                      f"({tf:.2f} s) + predict on {m_s} of {M} grid points scaled to M ({tp:.2f} s); workload {workload}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="C4r", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1: nccl (= RCCL over xGMI, the default) or gloo (rehearsal of the "
@@ -69,6 +160,7 @@ def main():
 
     import gaussian_process_liouville_equation_amd as pkg
     from gaussian_process_liouville_equation_amd import _capi as c
+    from gaussian_process_liouville_equation_amd import parallel
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,35 +174,34 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group("gloo")
+    if args.workload == "C4opt":
+        return opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev)
 
     N, G, kernel = WORKLOADS[args.workload]
     cplx = kernel == "complex"
     M = G * G
     by_element = args.shard == "elements" and world > 1
     X, y, grid, theta = synthetic(N, G, 20240607 + 1 + (rank if by_element else 0), kernel)
-    # contiguous grid slice of this rank (padded to equal length so that all_gather_into_tensor applies); a rank that owns a
-    # whole element predicts the whole grid
-    per = M if by_element else (M + world - 1) // world
-    lo, hi = (0, M) if by_element else (min(M, rank * per), min(M, (rank + 1) * per))
 
     stream = torch.cuda.current_stream()
     api = pkg.open_api(dev, stream=stream.cuda_stream)  # the library runs on torch's current stream
     api.enable_timing(True)
     dX = torch.from_numpy(X).cuda()
     dy = torch.from_numpy(np.ascontiguousarray(y).view(np.float64) if cplx else y).cuda()
-    dgrid = torch.from_numpy(grid[lo:hi].copy()).cuda()
-    # rows: mean, variance, cut-off mean (real: 1 + 1 + 1, complex: 2 + 1 + 2 doubles per point)
-    out_local = torch.zeros(5 if cplx else 3, per, dtype=torch.float64, device="cuda")
-    out_full = torch.zeros(world * out_local.shape[0], per, dtype=torch.float64, device="cuda") if world > 1 and not by_element else None
+    dgrid_all = torch.from_numpy(grid).cuda()
     dp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))
     th = np.ascontiguousarray(theta)
     sc, ps = (c.ComplexFitScalars() if cplx else c.RealFitScalars()), c.PredictScalars()
     flags = c.CALC_ERROR | c.CALC_AVERAGE | c.IO_DEVICE
     thp = th.ctypes.data_as(C.POINTER(C.c_double))
-    # complex outputs are interleaved (re, im) pairs: rows 0-1 / 3-4 of out_local viewed as one buffer of 2 * per doubles
-    o_mean, o_var, o_cut = (out_local[0:2], out_local[2], out_local[3:5]) if cplx else (out_local[0], out_local[1], out_local[2])
+    # rows: mean, variance, cut-off mean (real: 1 + 1 + 1, complex: 2 + 1 + 2 doubles per point)
+    rows = 5 if cplx else 3
+    alloc = lambda Cc, per: torch.zeros(Cc, per, dtype=torch.float64, device="cuda")
+    # by_element: a rank that owns a whole element predicts the whole grid; nothing is gathered
+    shard = parallel.GridShardedStep(M, rows, alloc, via_host=args.backend == "gloo", shard=not by_element)
+    lo, hi = shard.lo, shard.hi
 
-    def step():
+    def fit():
         h = C.c_void_p()
         if cplx:
             st = api.lib.gple_complex_fit_create(api.ctx, thp, dp(dX), dp(dy), N, flags, None, C.byref(h))
@@ -118,17 +209,21 @@ def main():
             st = api.lib.gple_real_fit_create(api.ctx, thp, dp(dX), dp(dy), 0, N, flags, None, C.byref(h))
         if st != 0:
             raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
+        return h
+
+    def predict_slice(h, lo, hi, out):
+        # complex outputs are interleaved (re, im) pairs: rows 0-1 / 3-4 of `out` viewed as one buffer of 2 * per doubles
+        o_mean, o_var, o_cut = (out[0:2], out[2], out[3:5]) if cplx else (out[0], out[1], out[2])
         fn = api.lib.gple_complex_predict if cplx else api.lib.gple_real_predict
-        st = fn(api.ctx, h, dp(dgrid), hi - lo, c.IO_DEVICE, None, dp(o_mean), dp(o_var), dp(o_cut), C.byref(ps))
+        st = fn(api.ctx, h, dp(dgrid_all[lo:hi]), hi - lo, c.IO_DEVICE, None, dp(o_mean), dp(o_var), dp(o_cut), C.byref(ps))
         if st != 0:
             raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
-        if world > 1 and not by_element:
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(out_full, out_local)  # RCCL, ordered on the same stream as the kernels
-            else:
-                host = torch.empty(out_full.shape, dtype=out_full.dtype)
-                dist.all_gather_into_tensor(host, out_local.cpu())
-                out_full.copy_(host)
+
+    last = {}
+
+    def step():
+        h, full = shard.run(fit, predict_slice)  # fit + this rank's slice + all-gather (RCCL on the same stream as the kernels)
+        last["full"] = full
         # the fit's scalar members (error, population, <r>, purity): the one host synchronisation of the step; fit and
         # predict above only enqueue
         st = (api.lib.gple_complex_fit_get_scalars if cplx else api.lib.gple_real_fit_get_scalars)(h, C.byref(sc))
@@ -154,10 +249,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # sanity of the gathered grid: every rank must now hold all M points (checked once, outside the timed region)
-        full = out_local if by_element else out_full.view(world, out_local.shape[0], per).permute(1, 0, 2).reshape(out_local.shape[0], world * per)[:, :M]
-        if not bool(torch.isfinite(full).all()):
-            raise RuntimeError("gathered prediction contains non-finite values")
+    # sanity of the (gathered) grid: every rank must now hold all M points (checked once, outside the timed region)
+    full = last["full"]
+    if tuple(full.shape) != (rows, M) or not bool(torch.isfinite(full).all()):
+        raise RuntimeError("gathered prediction has the wrong shape or contains non-finite values")
     ms_per_step = 1e3 * elapsed / args.steps
 
     _, fit_total, fit_cnt = api.timing(0)
@@ -167,21 +262,21 @@ def main():
     launches_per_step = pk_cnt / max(1, args.steps)
     m_local = hi - lo
     # algorithmic flops of the dominant kernel: triangular contraction ||T k*||^2 = N(N+1) flops per test point
-    # (the reference's row * K^-1 * row^T form is 2 N^2 per point; DESIGN.md §roofline), split over the launches
+    # (the reference's row * K^-1 * row^T form is 2 N^2 per point; DESIGN.md §4), split over the launches
     # complex GP = real GP on [Re; Im]: 2 typed rows per point against the 2N x 2N factor
-    nn, rows = (2 * N, 2 * m_local) if cplx else (N, m_local)
-    flops = float(rows) * nn * (nn + 1) / max(1.0, launches_per_step)
+    nn, trows = (2 * N, 2 * m_local) if cplx else (N, m_local)
+    flops = float(trows) * nn * (nn + 1) / max(1.0, launches_per_step)
     achieved = flops / (pk_ms * 1e-3) / 1e12 if pk_ms > 0 else 0.0
-    # HBM traffic of one rownorm_kernel launch: PMC counters cannot be read from inside the run; the value committed under
-    # profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950 guide
-    # prescribes) is reported when it was taken on this workload at this GPU count
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if tj.get("workload") == args.workload and world == 1:
-            traffic = tj["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+    traffic, traffic_src = traffic_for(args.workload, world)
+    # SURVEY.md §8(d) per-step models (per element; the complex element in its real [Re; Im] embedding: n = 2N, 2M typed rows)
+    t_s = ms_per_step * 1e-3
+    nM, TM = (2 * M, 128) if cplx else (M, 128)
+    F_fit = float(nn) ** 3 + 4.0 * nn * nn                       # factor + inverse factor + two solves (N^3 + 4 N^2)
+    F_contract = float(nM) * nn * (nn + 1)                       # executed (triangular) form of the variance contraction
+    F_contract_ref = (32.0 if cplx else 2.0) * M * N * N        # the reference's row W row^T form
+    E = (3.0 if cplx else 1.0) * (N * N / 2.0 + N * N / 2.0 + float(M) * N)  # exp evaluations: K, purity K1, K*
+    B_fused = 24.0 * N + 16.0 * M + 8.0 * rows * M + 16.0 * nn * nn + np.ceil(nM / TM) * 8.0 * nn * (nn + 1) / 2.0
+    B_mat = B_fused + 24.0 * nM * nn                             # + write K* once, read it twice (mean, variance)
     result = {
         "metric": "GP fit+predict ms/step (N samples, M grid pts)",
         "value": round(ms_per_step, 4),
@@ -200,28 +295,113 @@ def main():
                                    f"grid-sharded x{world}, replicated fit, {'RCCL' if args.backend == 'nccl' else 'gloo (host)'} all-gather") if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "kernel": "rownorm_kernel (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
                      "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
-                     "traffic": traffic, "kernel_ms": round(pk_ms, 4), "launches_per_step": launches_per_step,
+                     "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(pk_ms, 4), "launches_per_step": launches_per_step,
                      "algorithmic_flops_per_launch": flops,
                      "reference_form_flops_per_launch": (32.0 if cplx else 2.0) * m_local * N * N / max(1.0, launches_per_step)},
         "phases_ms": {"fit_device": round(fit_total / max(1, fit_cnt), 4), "predict_device": round(pred_total / max(1, pred_cnt), 4),
                       "rownorm_kernel_per_step": round(pk_total / max(1, args.steps), 4)},
+        # SURVEY.md §8(d) report fields, whole step, whole job (all ranks together process one element's step)
+        "mfma_frac_step": round((F_fit + F_contract) / t_s / (FP64_PEAK_TFLOPS * 1e12), 4),
+        "mfma_frac_step_reference_form": round((F_fit + F_contract_ref) / t_s / (FP64_PEAK_TFLOPS * 1e12), 4),
+        "hbm_gbps_fused": round(B_fused / t_s / 1e9, 2),
+        "hbm_gbps_mat": round(B_mat / t_s / 1e9, 2),
+        "exp_rate": round(E / t_s, 1),
+        "models": {"F_fit": F_fit, "F_contract_triangular": F_contract, "F_contract_reference_form": F_contract_ref, "exp_count": E,
+                   "B_fused_bytes": B_fused, "B_mat_bytes": B_mat, "T_M": TM,
+                   "note": "B_fused: inputs + outputs + K and T written once + the lower triangle of T re-read per 128-row tile (L2/MALL-resident); "
+                           "B_mat adds the materialised K* (8 B written, 16 B read per entry) = the reference-equivalent byte model; "
+                           "hbm_gbps_* = model bytes / step time, not counter traffic (that is roofline.traffic)"},
     }
-    if rank == 0 and not args.no_cpu_baseline and world == 1 and not cplx:
-        from oracle import binding
-        ora = binding.load()
-        t0 = time.perf_counter()
-        fo = ora.real_fit(theta, X, y, 3)
-        tf = time.perf_counter() - t0
-        # bounded sample: the full fit + a slice of the grid, extrapolated linearly in M (rows are independent)
-        m_s = min(M, 16384)
-        t0 = time.perf_counter()
-        ora.real_predict(fo, grid[:m_s])
-        tp = (time.perf_counter() - t0) * (M / m_s)
-        result["cpu_baseline"] = {"value": round(1e3 * (tf + tp), 1), "unit": "ms/step", "cores": ora.num_threads, "kind": "port",
-                                  "sample": f"oracle (CPU restatement, OpenMP): full fit N={N} ({tf:.2f} s) + predict on {m_s} of {M} grid points scaled to M ({tp:.2f} s)"}
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(args.workload, N, G, kernel, X, y, grid, theta)
     if rank == 0:
         print(json.dumps(result), flush=True)
     api.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev):
+    """--workload C4opt: the optimiser's inner loop of BASELINE configs[3] (opt.cpp:441-482, 844-870; main.cpp:35).
+    One step = full_loose value + gradient = loose_function of 2 real + 1 complex element (N = 4096, 5N extra points each),
+    every element on its own context / HIP stream (kernels.ApiPool), data resident (gple_objective_*).  With N ranks the
+    elements are dealt out to the ranks (element e -> rank e mod world, parallel.element_owner) and the scalars all-reduced."""
+    from gaussian_process_liouville_equation_amd import kernels as K
+    N = WORKLOADS["C4opt"][0]
+    elems = [("real", 0), ("complex", 1), ("real", 2)]  # reference order (0,0), (1,0), (1,1)
+    mine = [i for i in range(3) if parallel.element_owner(i, world) == rank]
+    pool = K.ApiPool(n=max(1, len(mine)), device=dev)
+    objs, thetas = {}, {}
+    for slot, i in enumerate(mine):
+        kernel = elems[i][0]
+        X, y, _, theta = synthetic(N, 1, 20240607 + 3 + i, kernel)
+        Xe, ye = extra_points(X, 20240607 + 30 + i, kernel)
+        api = pool.api_for(slot)
+        api.enable_timing(True)
+        objs[i] = api.objective(X, np.asarray(y, dtype=complex), Xe, ye)
+        thetas[i] = theta
+
+    def step():
+        res = pool.map(lambda api, i: objs[i](thetas[i], want_grad=True), mine)
+        vals = {i: [v] + list(g) + [0.0] * (8 - len(g)) for i, (v, g) in zip(mine, res)}
+        allv = parallel.allgather_element_scalars(vals, 3, 9, device="cuda" if (world > 1 and args.backend == "nccl") else "cpu")
+        return allv
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    for slot in range(len(mine)):
+        pool.api_for(slot).enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allv = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not bool(torch.isfinite(allv).all()):
+        raise RuntimeError("non-finite objective value or gradient")
+    ms = 1e3 * elapsed / args.steps
+    # derivative GEMMs dK * K^-1 (kernel.cpp:354): HIP events of the library around each launch; 2 n^3 flops each
+    gemm_ms, gemm_cnt, gemm_flops, per_elem = 0.0, 0, 0.0, {}
+    for slot, i in enumerate(mine):
+        api = pool.api_for(slot)
+        _, tot, cnt = api.timing(3)
+        _, ftot, fcnt = api.timing(0)
+        _, ptot, pcnt = api.timing(1)
+        n = 2 * 4096 if elems[i][0] == "complex" else 4096
+        gemm_ms, gemm_cnt, gemm_flops = gemm_ms + tot, gemm_cnt + cnt, gemm_flops + cnt * 2.0 * n ** 3
+        per_elem[f"element_{i}_{elems[i][0]}"] = {"fit_with_derivatives_ms": round(ftot / max(1, fcnt), 3), "predict_5N_ms": round(ptot / max(1, pcnt), 3),
+                                                   "deriv_gemm_ms_each": round(tot / max(1, cnt), 3), "deriv_gemms_per_eval": cnt / max(1, args.steps)}
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # SURVEY.md §8(d) minimum-work gradient model per element: F_grad = 2 D n^3 + 2 n^3 (D = 2 length parameters; real n = N).
+    # The complex element in the [Re; Im] embedding runs 6 GEMMs of size 2N (DESIGN.md §3).
+    F_eval = sum((6 if k == "complex" else 2) * 2.0 * ((2 * N if k == "complex" else N) ** 3) + ((2 * N if k == "complex" else N) ** 3) for k, _ in elems)
+    result = {
+        "metric": "GP fit+predict ms/step (N samples, M grid pts)", "value": round(ms, 4), "unit": "ms/step", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"C4opt: opt.cpp inner loop, full_loose value+gradient of 2 real + 1 complex element, N={N}, 5N={5 * N} extra points each",
+                   "N": N, "M": 5 * N, "parallelism": "3 elements on 3 HIP streams of one GPU" if world == 1 else f"elements dealt out over {world} ranks, scalars all-reduced"},
+        "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<128,128> (dK * K^-1 of the LOOCV gradient, kernel.cpp:354)", "achieved": round(achieved, 3),
+                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel_ms": round(gemm_ms / max(1, gemm_cnt), 4), "launches_per_step": gemm_cnt / max(1, args.steps),
+                     "note": "the three elements run concurrently on one GPU, so a GEMM's event time includes what it shares with the other streams"},
+        "mfma_frac_step": round(F_eval / (ms * 1e-3) / (FP64_PEAK_TFLOPS * 1e12), 4),
+        "phases_ms": per_elem,
+    }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    for o in objs.values():
+        o.release()
+    pool.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -93,6 +93,11 @@ struct gple_ctx: gple::Ctx
 	std::vector<PoolEntry> pool;
 	std::mutex pool_mu;
 	std::mutex call_mu; // serialises fit / predict calls that share the pooled scratch
+	// Lifetime: the creator holds one reference, every live fit / objective one more.  gple_ctx_destroy() closes the context
+	// (entry points that take it return GPLE_ERR_STATE from then on) and drops the creator's reference; the device buffers,
+	// the stream and the struct itself go when the last handle created from it is released.
+	std::atomic<int> refs{1};
+	std::atomic<bool> closed{false};
 
 	double* acquire(size_t bytes, hipError_t* err)
 	{
@@ -121,6 +126,26 @@ struct gple_ctx: gple::Ctx
 			if (e.p == p) e.used = false;
 	}
 };
+
+static void ctx_retain(gple_ctx* c) { c->refs.fetch_add(1); }
+// drops one reference; the last one tears the context down
+static void ctx_drop(gple_ctx* ctx)
+{
+	if (ctx->refs.fetch_sub(1) != 1) return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	for (auto& e : ctx->pool) (void)hipFree(e.p);
+	if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
+	timer_collect(ctx);
+	for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
+	if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+#define GPLE_OPEN(ctx)                                  \
+	do                                                  \
+	{                                                   \
+		if ((ctx)->closed.load()) return GPLE_ERR_STATE; \
+	} while (0)
 
 namespace
 {
@@ -200,6 +225,7 @@ struct FitCommon
 	{
 		if (!ctx) return;
 		for (double* p : {Xt, ys, T, v, w, wx, W, dv, sdev}) ctx->give_back(p);
+		ctx_drop(ctx); // the reference fit_common() took
 	}
 };
 struct gple_real_fit: FitCommon
@@ -240,6 +266,7 @@ namespace
 		hipStream_t st = ctx->stream;
 		const bool dev = flags & GPLE_IO_DEVICE;
 		f->ctx = ctx;
+		ctx_retain(ctx); // a fit keeps its context alive (released in ~FitCommon)
 		f->N = static_cast<int>(N);
 		f->Np = static_cast<int>(round_up(N, NPAD));
 		f->n_total = f->is_complex ? 2 * f->Np : f->Np;
@@ -325,7 +352,9 @@ namespace
 			g.A = Dd, g.lda = nt, g.B = f->W, g.ldb = nt, g.C = C.p, g.ldc = nt;
 			g.M = nt, g.N = nt, g.K = nt, g.batch = 1, g.alpha = 1.0, g.beta = 0.0, g.krange = K_FULL, g.lower_only = 0;
 			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
+			timer_start(ctx, GPLE_TIMER_DERIV_GEMM);
 			GPLE_HIP(ctx, launch_gemm(st, g, gemm_pick_tile(nt, nt, 1, false)));
+			timer_stop(ctx, GPLE_TIMER_DERIV_GEMM);
 			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, C.p, nt, nt, 0, -1.0, dwd.p + static_cast<size_t>(1 + d) * nt));
 		}
 		// noise: dW = -2 sf^2 sn W W (:358)
@@ -432,7 +461,9 @@ namespace
 			g.A = D.p, g.lda = nt, g.B = f->W, g.ldb = nt, g.C = C.p, g.ldc = nt;
 			g.M = nt, g.N = nt, g.K = nt, g.batch = 1, g.alpha = 1.0, g.beta = 0.0, g.krange = K_FULL, g.lower_only = 0;
 			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
+			timer_start(ctx, GPLE_TIMER_DERIV_GEMM);
 			GPLE_HIP(ctx, launch_gemm(st, g, gemm_pick_tile(nt, nt, 1, false)));
+			timer_stop(ctx, GPLE_TIMER_DERIV_GEMM);
 			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, C.p, nt, nt, 0, -1.0, dwd.p + static_cast<size_t>(ip) * nt));
 			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, C.p, nt, nt, Np, -1.0, dwx.p + static_cast<size_t>(ip) * Np));
 		}
@@ -642,19 +673,19 @@ extern "C"
 	int gple_ctx_destroy(gple_ctx* ctx)
 	{
 		if (!ctx) return GPLE_OK;
-		(void)hipSetDevice(ctx->device);
-		(void)hipStreamSynchronize(ctx->stream);
-		for (auto& e : ctx->pool) (void)hipFree(e.p);
-		if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
-		timer_collect(ctx);
-		for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
-		if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
-		delete ctx;
+		if (ctx->closed.exchange(true)) return GPLE_ERR_STATE; // destroyed twice while handles keep it alive
+		{
+			std::lock_guard<std::mutex> lk(ctx->call_mu); // a call in flight on another thread finishes first
+			(void)hipSetDevice(ctx->device);
+			(void)hipStreamSynchronize(ctx->stream);
+		}
+		ctx_drop(ctx);
 		return GPLE_OK;
 	}
 	int gple_ctx_trim(gple_ctx* ctx, size_t* bytes_freed)
 	{
 		if (!ctx) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		GPLE_HIP(ctx, hipStreamSynchronize(ctx->stream)); // nothing in flight may still be using an idle buffer
@@ -678,6 +709,7 @@ extern "C"
 	int gple_ctx_synchronize(gple_ctx* ctx)
 	{
 		if (!ctx) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		timer_collect(ctx);
@@ -688,17 +720,19 @@ extern "C"
 	int gple_ctx_enable_timing(gple_ctx* ctx, int on)
 	{
 		if (!ctx) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		GPLE_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		timer_collect(ctx); // intervals still in flight belong to the old accumulators
 		ctx->timing = on != 0;
-		for (int w = 0; w < 3; ++w) ctx->t_last[w] = ctx->t_total[w] = 0.0, ctx->t_count[w] = 0;
+		for (int w = 0; w < Ctx::NTIMERS; ++w) ctx->t_last[w] = ctx->t_total[w] = 0.0, ctx->t_count[w] = 0;
 		return GPLE_OK;
 	}
 	int gple_ctx_get_timing(gple_ctx* ctx, gple_timer which, double* last_ms, double* total_ms, long* count)
 	{
-		if (!ctx || which < 0 || which > 2) return GPLE_ERR_BAD_ARG;
+		if (!ctx || static_cast<int>(which) < 0 || static_cast<int>(which) >= Ctx::NTIMERS) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		GPLE_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -714,6 +748,7 @@ extern "C"
 		int same_features, unsigned flags, double* K, double* dK)
 	{
 		if (!ctx || !theta || !K || (R && !left) || (C && !right)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		if (R == 0 || C == 0) return GPLE_OK;
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
@@ -743,6 +778,7 @@ extern "C"
 		double* factor)
 	{
 		if (!ctx || (M && (!prediction || !variance || !factor))) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		if (M == 0) return GPLE_OK;
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
@@ -832,6 +868,7 @@ extern "C"
 		unsigned flags, gple_real_fit_scalars* scalars, gple_real_fit** out)
 	{
 		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 20)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		*out = nullptr;
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
@@ -902,8 +939,9 @@ extern "C"
 		if (!fit) return GPLE_OK;
 		if (fit->refs.fetch_sub(1) == 1)
 		{
-			(void)hipStreamSynchronize(fit->ctx->stream);
-			delete fit;
+			(void)hipSetDevice(fit->ctx->device);
+			(void)hipStreamSynchronize(fit->ctx->stream); // work that still reads the fit's buffers
+			delete fit;                                   // may drop the last reference on a destroyed context
 		}
 		return GPLE_OK;
 	}
@@ -1080,6 +1118,7 @@ extern "C"
 		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars)
 	{
 		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
 	}
 
@@ -1134,6 +1173,7 @@ extern "C"
 		gple_complex_fit_scalars* scalars, gple_complex_fit** out)
 	{
 		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 19)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		*out = nullptr;
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
@@ -1229,8 +1269,9 @@ extern "C"
 		if (!fit) return GPLE_OK;
 		if (fit->refs.fetch_sub(1) == 1)
 		{
-			(void)hipStreamSynchronize(fit->ctx->stream);
-			delete fit;
+			(void)hipSetDevice(fit->ctx->device);
+			(void)hipStreamSynchronize(fit->ctx->stream); // work that still reads the fit's buffers
+			delete fit;                                   // may drop the last reference on a destroyed context
 		}
 		return GPLE_OK;
 	}
@@ -1303,6 +1344,7 @@ extern "C"
 		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars)
 	{
 		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
 	}
 
@@ -1359,6 +1401,7 @@ extern "C"
 		const double* y_extra, size_t M_extra, double* value, double* grad)
 	{
 		if (!ctx || !x || !X || !y || !value || (n != 4 && n != 8) || (M_extra && (!X_extra || !y_extra))) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		std::vector<double> lab(M_extra);
 		for (size_t i = 0; i < M_extra; ++i) lab[i] = y_extra[2 * i];
 		return loose_eval(ctx, x, n, X, y, N, X_extra, y_extra, lab.data(), M_extra, 0u, value, grad);
@@ -1375,12 +1418,14 @@ extern "C"
 		size_t M_extra, gple_objective** out)
 	{
 		if (!ctx || !X || !y || !out || N == 0 || (M_extra && (!X_extra || !y_extra))) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		*out = nullptr;
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		gple_objective* o = new (std::nothrow) gple_objective;
 		if (!o) return GPLE_ERR_ALLOC;
 		o->ctx = ctx, o->N = N, o->M = M_extra;
+		ctx_retain(ctx); // dropped in gple_objective_release
 		hipStream_t st = ctx->stream;
 		hipError_t e = hipSuccess;
 		auto up = [&](double*& dst, const double* src, size_t n) {
@@ -1396,7 +1441,9 @@ extern "C"
 		{
 			for (double* p : {o->X, o->y, o->Xe, o->ye, o->lab}) ctx->give_back(p);
 			delete o;
-			return record_hip_error(ctx, e, "objective upload", __LINE__);
+			const int status = record_hip_error(ctx, e, "objective upload", __LINE__);
+			ctx_drop(ctx);
+			return status;
 		}
 		*out = o;
 		return GPLE_OK;
@@ -1404,14 +1451,18 @@ extern "C"
 	int gple_objective_eval(gple_objective* o, const double* x, size_t n, double* value, double* grad)
 	{
 		if (!o || !x || !value || (n != 4 && n != 8)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(o->ctx);
 		return loose_eval(o->ctx, x, n, o->X, o->y, o->N, o->Xe, o->ye, o->lab, o->M, GPLE_IO_DEVICE, value, grad);
 	}
 	int gple_objective_release(gple_objective* o)
 	{
 		if (!o) return GPLE_OK;
-		(void)hipStreamSynchronize(o->ctx->stream);
-		for (double* p : {o->X, o->y, o->Xe, o->ye, o->lab}) o->ctx->give_back(p);
+		gple_ctx* ctx = o->ctx;
+		(void)hipSetDevice(ctx->device);
+		(void)hipStreamSynchronize(ctx->stream);
+		for (double* p : {o->X, o->y, o->Xe, o->ye, o->lab}) ctx->give_back(p);
 		delete o;
+		ctx_drop(ctx);
 		return GPLE_OK;
 	}
 
@@ -1451,6 +1502,7 @@ extern "C"
 	int gple_nlml(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, double* value, double* grad)
 	{
 		if (!ctx || !x || !X || !y || !value || N == 0) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
@@ -1479,6 +1531,7 @@ extern "C"
 		double* mean)
 	{
 		if (!ctx || !x || !X || !y || N == 0 || (M && (!Xs || !mean))) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
 		if (M == 0) return GPLE_OK;
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));

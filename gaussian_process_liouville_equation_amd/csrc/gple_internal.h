@@ -85,9 +85,10 @@ namespace gple
 		bool timing = false;
 		std::vector<hipEvent_t> ev_free;
 		std::vector<TimedSpan> pending;
-		TimedSpan open_span[4] = {}; // per gple_timer; [3] is unused padding
-		double t_last[3] = {0, 0, 0}, t_total[3] = {0, 0, 0};
-		long t_count[3] = {0, 0, 0};
+		static constexpr int NTIMERS = 4; // gple_timer
+		TimedSpan open_span[NTIMERS] = {};
+		double t_last[NTIMERS] = {0, 0, 0, 0}, t_total[NTIMERS] = {0, 0, 0, 0};
+		long t_count[NTIMERS] = {0, 0, 0, 0};
 	};
 	// one interval per rownorm_kernel launch (GPLE_TIMER_PREDICT_KERNEL)
 	void chunk_timer_start(Ctx* c);

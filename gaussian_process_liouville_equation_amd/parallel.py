@@ -50,6 +50,33 @@ def sharded_predict(predict_slice, grid, group=None):
     return allgather_rows(local, M, group)
 
 
+class GridShardedStep:
+    """One fit + grid-predict step with the grid split over the ranks — the step `bench.py --gpus N` times and
+    tests/test_distributed_gloo.py drives on CPU (same code, different backends plugged in).
+
+    fit()                         -> handle (replicated on every rank: see the module docstring)
+    predict_slice(h, lo, hi, out) -> fills out[:, :hi - lo] (C rows: mean, variance, cut-off mean, ...) for grid rows [lo, hi)
+    `local` is this rank's (C, per) buffer, allocated once by `alloc(C, per)`; `via_host` gathers through host memory (gloo
+    rehearsal with device tensors)."""
+
+    def __init__(self, M, C, alloc, group=None, via_host=False, shard=True):
+        # shard=False: this rank owns a whole element and predicts the whole grid itself (nothing is gathered)
+        self.world = dist.get_world_size(group) if (shard and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if (shard and dist.is_initialized()) else 0
+        self.M, self.group, self.via_host = M, group, via_host
+        self.lo, self.hi, self.per = shard_bounds(M, self.rank, self.world)
+        self.local = alloc(C, self.per)
+
+    def run(self, fit, predict_slice):
+        h = fit()
+        predict_slice(h, self.lo, self.hi, self.local)
+        if self.world == 1:
+            return h, self.local[:, :self.M]
+        if self.via_host:
+            return h, allgather_rows(self.local.cpu(), self.M, self.group).to(self.local.device)
+        return h, allgather_rows(self.local, self.M, self.group)
+
+
 def element_owner(index, world):
     """rank that fits density-matrix element number `index` (reference order: (0,0), (1,0), (1,1), ...)."""
     return index % world

@@ -33,7 +33,7 @@ extern "C" {
 #define GPLE_ERR_BAD_ARG 1
 #define GPLE_ERR_HIP 2
 #define GPLE_ERR_ALLOC 3
-#define GPLE_ERR_STATE 4 /* e.g. derivative output requested from a fit built without GPLE_CALC_DERIVATIVE */
+#define GPLE_ERR_STATE 4 /* e.g. derivative output requested from a fit built without GPLE_CALC_DERIVATIVE; call on a destroyed context */
 
 /* The three bools of the Training*Kernel constructors (kernel.h:128-134, complex_kernel.h:167-173). */
 #define GPLE_CALC_ERROR 0x1u
@@ -104,6 +104,12 @@ typedef enum gple_complex_array {
 /* ---- context ------------------------------------------------------------------------------------- */
 /* device: HIP device ordinal; stream: a hipStream_t to run on, or NULL for a stream owned by the context. */
 int gple_ctx_create(int device, void* stream, gple_ctx** out);
+/* Lifetime rule: every fit / objective handle holds a reference on the context it was created from.  gple_ctx_destroy()
+ * drains the stream, CLOSES the context (every entry point that takes `ctx` returns GPLE_ERR_STATE from then on) and drops
+ * the creator's reference; device buffers, the stream and the context itself are freed when the last handle created from it
+ * is released.  Handle-only calls (*_fit_get_scalars, *_fit_get, *_fit_release, gple_objective_release) therefore stay valid
+ * after the destroy and return a status instead of touching freed memory.  A second destroy of a context that handles
+ * still keep alive returns GPLE_ERR_STATE; a caller-provided stream must outlive the last handle. */
 int gple_ctx_destroy(gple_ctx* ctx);
 int gple_ctx_synchronize(gple_ctx* ctx);
 /* The context keeps every device buffer it ever needed in a grow-only pool (no hipMalloc on the steady-state path; a single
@@ -122,7 +128,8 @@ const char* gple_ctx_last_error(const gple_ctx* ctx);
 typedef enum gple_timer {
 	GPLE_TIMER_FIT = 0,            /* whole *_fit_create call (device side)                 */
 	GPLE_TIMER_PREDICT = 1,        /* whole *_predict call (device side)                    */
-	GPLE_TIMER_PREDICT_KERNEL = 2  /* the MFMA row-norm kernel of *_predict alone; count = its launches */
+	GPLE_TIMER_PREDICT_KERNEL = 2, /* the MFMA row-norm kernel of *_predict alone; count = its launches */
+	GPLE_TIMER_DERIV_GEMM = 3      /* the dK * K^-1 MFMA GEMM of a GPLE_CALC_DERIVATIVE fit (kernel.cpp:354); count = its launches */
 } gple_timer;
 int gple_ctx_enable_timing(gple_ctx* ctx, int on);
 /* Synchronises the stream, then: last = milliseconds of the most recent interval; total / count = accumulated since

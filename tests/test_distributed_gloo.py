@@ -34,6 +34,16 @@ def _worker(rank, world, port, M, out_dir):
         return torch.from_numpy(np.stack([p["prediction"], p["variance"], p["cutoff"]]))
 
     full = parallel.sharded_predict(predict_slice, torch.from_numpy(Xs))
+
+    # the step function bench.py --gpus N times (parallel.GridShardedStep), with the oracle plugged in for fit and predict
+    def fill(h, lo, hi, out):
+        p = ora.real_predict(h, Xs[lo:hi])
+        out[:, :hi - lo] = torch.from_numpy(np.stack([p["prediction"], p["variance"], p["cutoff"]]))
+
+    step = parallel.GridShardedStep(M, 3, lambda C, per: torch.zeros(C, per, dtype=torch.float64))
+    h, full_step = step.run(lambda: ora.real_fit(theta, X, y, 3), fill)
+    assert (step.lo, step.hi, step.per) == parallel.shard_bounds(M, rank, world)
+    np.save(os.path.join(out_dir, f"step_{rank}.npy"), full_step.numpy())
     # per-element scalars: element e is owned by rank e % world
     mine = {e: [float(e), fit.scalars["population"] * (e + 1)] for e in range(3) if parallel.element_owner(e, world) == rank}
     scal = parallel.allgather_element_scalars(mine, 3, 2)
@@ -56,6 +66,7 @@ def test_grid_sharded_predict_matches_unsharded(tmp_path, M):
         got = np.load(tmp_path / f"full_{r}.npy")
         assert got.shape == ref.shape
         assert np.array_equal(got, ref)  # same code on the same rows: bit-identical, including the padded tail handling
+        assert np.array_equal(np.load(tmp_path / f"step_{r}.npy"), ref)  # the bench's step function gives the same grid
         scal = np.load(tmp_path / f"scal_{r}.npy")
         assert np.allclose(scal[:, 0], [0.0, 1.0, 2.0]) and np.allclose(scal[:, 1], fit.scalars["population"] * np.array([1, 2, 3]))
 

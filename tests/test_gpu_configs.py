@@ -1,0 +1,465 @@
+"""GPU (MI355X): every BASELINE.json config at its full size, through the C-ABI.
+
+C1 is small enough for an element-wise run of the CPU oracle; C3 / C4 / C5 are checked through properties that do not
+depend on the size (residuals of the linear systems the getters claim to solve, the reference's own `row W row^T` variance
+form on a handful of rows evaluated by numpy, variance range, far-field limits, analytic population = grid quadrature,
+finite differences of the objective) — the oracle needs minutes to hours there.
+"""
+import numpy as np
+import pytest
+
+from gaussian_process_liouville_equation_amd import _capi as c
+from gaussian_process_liouville_equation_amd import kernels as K
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+X0, P0, SX, SP = -10.0, 14.112, 0.7086, 0.7056
+THETA_R = [1.0, SX, SP, 1e-2]                      # opt.cpp:286-305
+THETA_C = [1.0, 1.0, SX, SP, 1.0, SX, SP, 1e-2]    # opt.cpp:306-332
+
+
+def config_inputs(N, G, seed, cplx=False):
+    """SURVEY.md §8(d) synthetic inputs (the generator of bench.py): samples of the initial wave packet, exact labels,
+    the x-major / p-fastest G x G grid of input.cpp:37-70."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.normal([X0, P0], [SX, SP], size=(N, 2))
+    y = np.exp(-0.5 * (((X[:, 0] - X0) / SX) ** 2 + ((X[:, 1] - P0) / SP) ** 2)) / (2 * np.pi * SX * SP)
+    dx = 40.0 / G
+    xs = -20.0 + dx * np.arange(G)
+    ps = (P0 - np.pi / (2 * dx)) + (np.pi / dx / G) * np.arange(G)
+    gx, gp = np.meshgrid(xs, ps, indexing="ij")
+    grid = np.ascontiguousarray(np.stack([gx.ravel(), gp.ravel()], axis=1))
+    if cplx:
+        y = 0.5 * y * np.exp(0.5j * (X[:, 0] - X0))
+    return X, y, grid, dx * (np.pi / dx / G)
+
+
+def se(A, B, s, l0, l1):
+    d0 = (A[:, None, 0] - B[None, :, 0]) / l0
+    d1 = (A[:, None, 1] - B[None, :, 1]) / l1
+    return s * s * np.exp(-0.5 * (d0 ** 2 + d1 ** 2))
+
+
+def complex_rect_kernels(theta, A, B):
+    """K (real) and K~ (complex) between two point sets, complex_kernel.cpp:134-164 (no coincident points: delta = 0)."""
+    s, sR, lR0, lR1, sI, lI0, lI1, _ = theta
+    ss0, ss1 = lR0 ** 2 + lI0 ** 2, lR1 ** 2 + lI1 ** 2
+    sC = np.sqrt(sR * sI * (2 * lR0 * lI0 / ss0) * (2 * lR1 * lI1 / ss1))
+    KR, KI, KC = se(A, B, sR, lR0, lR1), se(A, B, sI, lI0, lI1), se(A, B, sC, np.sqrt(ss0 / 2), np.sqrt(ss1 / 2))
+    return s * s * (KR + KI), s * s * (KR - KI + 2j * KC)
+
+
+def probe_residual(K, W, nprobe=4, seed=0):
+    """max over a few random vectors z of ||K (W z) - z||_inf / (||K||_1 ||W||_1 ||z||_inf): K W = I without an N^3 product"""
+    rng = np.random.default_rng(seed)
+    Z = rng.standard_normal((K.shape[0], nprobe))
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    return np.abs(K @ (W @ Z) - Z).max() / (n1(K) * n1(W) * np.abs(Z).max())
+
+
+def check_real_grid_properties(fit, p, theta, grid, cell, far_mask):
+    kss = theta[0] ** 2 * (1 + theta[3] ** 2)
+    s = fit.scalars["rescale_factor"]
+    assert p["variance"].min() >= -1e-7 and p["variance"].max() <= kss + 1e-12
+    assert np.abs(p["prediction"][far_mask]).max() <= 1e-9 and np.abs(p["variance"][far_mask] - kss).max() <= 1e-9
+    assert np.all(np.abs(p["cutoff"]) <= np.abs(p["prediction"]) / s + 1e-15)
+    # analytic population (kernel.cpp:286-297) == grid quadrature of the uncut mean
+    quad = p["prediction"].sum() * cell / s
+    assert abs(quad - fit.scalars["population"]) <= 1e-6 * abs(fit.scalars["population"])
+
+
+# ---- C1: N = 256, 128 x 128 grid, real kernel — the reference's CPU-runnable config, element-wise against the oracle -------------
+def test_c1_exact_config_against_oracle(gpu, oracle):
+    N, G = 256, 128
+    X, y, grid, cell = config_inputs(N, G, 20240607 + 0)
+    fg, fo = gpu.real_fit(THETA_R, X, y, 3), oracle.real_fit(THETA_R, X, y, 3)
+    assert fg.scalars["info"] == 0
+    for k in ("population", "purity", "magnitude", "rescale_factor"):
+        assert abs(fg.scalars[k] - fo.scalars[k]) <= 1e-8 * abs(fo.scalars[k]), k
+    assert abs(fg.scalars["error"] - fo.scalars["error"]) <= 1e-6 * abs(fo.scalars["error"])
+    assert np.abs(fg.scalars["first_order_average"] - fo.scalars["first_order_average"]).max() <= 1e-8 * np.abs(fo.scalars["first_order_average"]).max()
+    pg, po = gpu.real_predict(fg, grid), oracle.real_predict(fo, grid)
+    scale = np.abs(po["prediction"]).max()
+    assert np.abs(pg["prediction"] - po["prediction"]).max() <= 1e-10 * scale      # mean 1e-10 * scale
+    assert np.abs(pg["variance"] - po["variance"]).max() <= 1e-9                    # variance abs 1e-9 * sf^2
+    assert np.abs(pg["cutoff"] - po["cutoff"]).max() <= 1e-9 * scale / fo.scalars["rescale_factor"]
+    check_real_grid_properties(fg, pg, THETA_R, grid, cell, np.abs(grid[:, 0] + 10) > 8)
+
+
+# ---- C3: N = 2048, 256 x 256 grid, complex kernel ----------------------------------------------------------------------------------
+def check_complex_fit_and_rows(gpu, fit, theta, X, grid, p, rows):
+    N = len(X)
+    Kc, Kt = fit.get(c.C_KERNEL), fit.get(c.C_PSEUDO)
+    P, Q, v, ys = fit.get(c.C_UPPER_LEFT), fit.get(c.C_LOWER_LEFT), fit.get(c.C_INVLBL), fit.get(c.C_LABEL)
+    # augmented system [K Kt; Kt* K] [P; Q] = [I; 0] on random probe vectors, and K v + Kt conj(v) = y
+    rng = np.random.default_rng(5)
+    Z = rng.standard_normal((N, 3)) + 1j * rng.standard_normal((N, 3))
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    scale = 50 * 2 * N * parity.EPS * (n1(Kc) + n1(Kt)) * (n1(P) + n1(Q)) * np.abs(Z).max()
+    assert np.abs(Kc @ (P @ Z) + Kt @ (Q @ Z) - Z).max() <= scale
+    assert np.abs(Kt.conj() @ (P @ Z) + Kc @ (Q @ Z)).max() <= scale
+    assert np.abs(Kc @ v + Kt @ v.conj() - ys).max() <= 1e-7 * np.abs(ys).max()
+    assert np.abs(P - P.conj().T).max() <= 1e-9 * np.abs(P).max()  # P Hermitian (complex_kernel.cpp:266)
+    # the reference's forms on a few grid rows (complex_kernel.cpp:608, 631-637), evaluated by numpy from the getters
+    k, kt = complex_rect_kernels(theta, grid[rows], X)
+    mu = k @ v + kt @ v.conj()
+    kss = theta[0] ** 2 * (theta[1] ** 2 + theta[4] ** 2 + theta[7] ** 2)
+    var = (kss - np.einsum("ij,jk,ik->i", k, P, k) - np.einsum("ij,jk,ik->i", kt, P.conj(), kt.conj())
+           - np.einsum("ij,jk,ik->i", kt, Q, k) - np.einsum("ij,jk,ik->i", k, Q.conj(), kt.conj())).real
+    assert np.abs(mu - p["prediction"][rows]).max() <= 1e-8 * max(np.abs(p["prediction"]).max(), 1e-300)
+    assert np.abs(var - p["variance"][rows]).max() <= 1e-6  # the reference's form cancels four N^2 sums of size ~cond
+    return kss
+
+
+@pytest.mark.parametrize("N,G,seed", [(2048, 256, 20240607 + 2)])
+def test_c3_full_size_complex(gpu, N, G, seed):
+    X, y, grid, _ = config_inputs(N, G, seed, cplx=True)
+    fit = gpu.complex_fit(THETA_C, X, y, 3)
+    assert fit.scalars["info"] == 0 and np.isfinite(fit.scalars["error"]) and np.isfinite(fit.scalars["purity"])
+    p = gpu.complex_predict(fit, grid)
+    near = np.argsort(((grid - [X0, P0]) ** 2).sum(axis=1))[:48]
+    rows = np.concatenate([near, np.arange(0, len(grid), len(grid) // 16)[:16]])
+    kss = check_complex_fit_and_rows(gpu, fit, THETA_C, X, grid, p, rows)
+    assert p["variance"].min() >= -1e-7 and p["variance"].max() <= kss + 1e-12
+    far = np.abs(grid[:, 0] + 10) > 8
+    assert np.abs(p["prediction"][far]).max() <= 1e-9 and np.abs(p["variance"][far] - kss).max() <= 1e-9
+    assert np.all(np.abs(p["cutoff"]) <= np.abs(p["prediction"]) / fit.scalars["rescale_factor"] + 1e-15)
+
+
+# ---- C4: N = 4096, 512 x 512 grid; 2 real + 1 complex element; the opt.cpp objective with 5N extra points -------------------------
+def test_c4_real_full_grid(gpu):
+    N, G = 4096, 512
+    X, y, grid, cell = config_inputs(N, G, 20240607 + 3)
+    fit = gpu.real_fit(THETA_R, X, y, 3)
+    assert fit.scalars["info"] == 0
+    p = gpu.real_predict(fit, grid)
+    assert len(p["variance"]) == G * G
+    check_real_grid_properties(fit, p, THETA_R, grid, cell, np.abs(grid[:, 0] + 10) > 8)
+    # mean and variance in the reference's form k W k^T (kernel.cpp:495, 512-513) on the rows nearest the packet
+    W, v = fit.get(c.R_INVERSE), fit.get(c.R_INVLBL)
+    rows = np.argsort(((grid - [X0, P0]) ** 2).sum(axis=1))[:64]
+    Ks = gpu.real_gram(THETA_R, grid[rows], X, False)
+    kss = THETA_R[0] ** 2 * (1 + THETA_R[3] ** 2)
+    assert np.abs(Ks @ v - p["prediction"][rows]).max() <= 1e-8 * np.abs(p["prediction"]).max()
+    assert np.abs((kss - np.einsum("ij,jk,ik->i", Ks, W, Ks)) - p["variance"][rows]).max() <= 1e-7
+
+
+def test_c4_complex_full_grid(gpu):
+    N, G = 4096, 512
+    X, y, grid, _ = config_inputs(N, G, 20240607 + 3, cplx=True)
+    fit = gpu.complex_fit(THETA_C, X, y, 3)
+    assert fit.scalars["info"] == 0 and np.isfinite(fit.scalars["purity"])
+    p = gpu.complex_predict(fit, grid)
+    assert len(p["variance"]) == G * G
+    rows = np.argsort(((grid - [X0, P0]) ** 2).sum(axis=1))[:32]
+    kss = check_complex_fit_and_rows(gpu, fit, THETA_C, X, grid, p, rows)
+    assert p["variance"].min() >= -1e-7 and p["variance"].max() <= kss + 1e-12
+    far = np.abs(grid[:, 0] + 10) > 8
+    assert np.abs(p["prediction"][far]).max() <= 1e-9 and np.abs(p["variance"][far] - kss).max() <= 1e-9
+    assert np.all(np.abs(p["cutoff"]) <= np.abs(p["prediction"]) / fit.scalars["rescale_factor"] + 1e-15)
+
+
+def extra_set(X, seed, cplx):
+    """5N validation points r_{i mod N} + N(0, std(r)^2) with exact labels (main.cpp:35, mc.cpp:59-94)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    N = len(X)
+    Xe = X[np.arange(5 * N) % N] + rng.normal(0.0, X.std(axis=0), size=(5 * N, 2))
+    ye = np.exp(-0.5 * (((Xe[:, 0] - X0) / SX) ** 2 + ((Xe[:, 1] - P0) / SP) ** 2)) / (2 * np.pi * SX * SP)
+    return Xe, (0.5 * ye * np.exp(0.5j * (Xe[:, 0] - X0)) if cplx else ye.astype(complex))
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_c4_loose_function_gradient_vs_central_differences(gpu, cplx):
+    """opt.cpp:441-482 at N = 4096 with 5N extra points.  The LOOCV part of the gradient is a true derivative; the validation
+    part mixes cut and uncut predictions (kernel.cpp:522 vs :527), so the finite difference is taken of the objective with
+    the labels of the extra set chosen where the cut-off factor is 1 for every point: there the two coincide."""
+    N = 4096
+    X, y, _, _ = config_inputs(N, 8, 20240607 + 3, cplx=cplx)
+    Xe, ye = extra_set(X, 77, cplx)
+    theta = np.array(THETA_C if cplx else THETA_R)
+    theta[-1] = 0.05  # a noise level at which the central difference of the objective is well resolved in fp64
+    # keep the extra points whose cut-off factor is 1 at theta (|mu|^2 >= 4 var): the gradient is then the objective's derivative
+    fit = (gpu.complex_fit if cplx else gpu.real_fit)(theta, X, y, 1)
+    pe = (gpu.complex_predict if cplx else gpu.real_predict)(fit, Xe)
+    keep = np.abs(pe["prediction"]) ** 2 >= 9.0 * pe["variance"]
+    assert keep.sum() > N  # most points near the packet qualify
+    Xe, ye = Xe[keep], ye[keep]
+    obj = gpu.objective(X, np.asarray(y, dtype=complex), Xe, ye)
+    val, grad = obj(theta, want_grad=True)
+    assert np.isfinite(val) and np.all(np.isfinite(grad))
+    free = [1, 2] if not cplx else [2, 3, 5, 6]  # the lengths: the parameters the optimiser actually moves (opt.cpp:1036-1040)
+    for ip in free:
+        h = 1e-5 * theta[ip]
+        tp, tm = theta.copy(), theta.copy()
+        tp[ip] += h
+        tm[ip] -= h
+        fd = (obj(tp, want_grad=False)[0] - obj(tm, want_grad=False)[0]) / (2 * h)
+        assert abs(fd - grad[ip]) <= 2e-4 * max(abs(fd), 1e-3 * np.abs(grad).max()), (ip, fd, grad[ip])
+    obj.release()
+
+
+def test_c4_three_elements_on_a_pool(gpu):
+    """configs[3]: the three elements of a 2-state density matrix (2 real + 1 complex GP) at N = 4096 built by TrainingKernels on
+    three contexts; aggregates equal those of the same elements built one after the other on one context."""
+    N = 4096
+    sets, params = {}, {}
+    for e, (i, j) in enumerate(K.element_order(2)):
+        X, y, _, _ = config_inputs(N, 8, 20240607 + 10 + e, cplx=i != j)
+        sets[(i, j)] = (X, np.asarray(y, dtype=complex))
+        params[(i, j)] = THETA_C if i != j else THETA_R
+    pool = K.ApiPool(n=3)
+    try:
+        kp = K.TrainingKernels(params, sets, True, True, False, api=pool)
+        k1 = K.TrainingKernels(params, sets, True, True, False, api=gpu)
+        for f in ("calculate_population", "calculate_purity"):
+            assert getattr(kp, f)() == getattr(k1, f)()
+        assert abs(kp.calculate_population() - 2.0) <= 0.2  # two diagonal elements each holding one normalised packet
+        assert np.isfinite(kp.calculate_purity())
+    finally:
+        pool.close()
+
+
+# ---- C5: N = 8192, 1024 x 1024 grid, NumPES = 3 -----------------------------------------------------------------------------------
+def test_c5_real_element_full_grid(gpu):
+    N, G = 8192, 1024
+    X, y, grid, cell = config_inputs(N, G, 20240607 + 4)
+    fit = gpu.real_fit(THETA_R, X, y, 3)
+    assert fit.scalars["info"] == 0
+    Kn, W, v, ys = fit.get(c.R_KERNEL), fit.get(c.R_INVERSE), fit.get(c.R_INVLBL), fit.get(c.R_LABEL)
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    assert probe_residual(Kn, W) <= 50 * N * parity.EPS
+    assert np.abs(Kn @ v - ys).max() <= 50 * N * parity.EPS * (n1(Kn) * np.abs(v).max() + np.abs(ys).max())
+    assert abs(((v / np.diag(W)) ** 2).sum() - fit.scalars["error"]) <= 1e-9 * fit.scalars["error"]
+    p = gpu.real_predict(fit, grid)
+    assert len(p["variance"]) == G * G
+    check_real_grid_properties(fit, p, THETA_R, grid, cell, np.abs(grid[:, 0] + 10) > 8)
+    rows = np.argsort(((grid - [X0, P0]) ** 2).sum(axis=1))[:32]
+    Ks = gpu.real_gram(THETA_R, grid[rows], X, False)
+    kss = THETA_R[0] ** 2 * (1 + THETA_R[3] ** 2)
+    assert np.abs(Ks @ v - p["prediction"][rows]).max() <= 1e-8 * np.abs(p["prediction"]).max()
+    assert np.abs((kss - np.einsum("ij,jk,ik->i", Ks, W, Ks)) - p["variance"][rows]).max() <= 3e-7
+
+
+def test_c5_three_state_elements_against_oracle(gpu, oracle):
+    """NumPES = 3 (stdafx.h:111 recompiled): 3 real + 3 complex elements; the GP code is generic in NumPES.
+    Sizes the oracle finishes in seconds; aggregates and their gradient packing HIP vs oracle."""
+    n = 3
+    sets, params = {}, {}
+    for e, (i, j) in enumerate(K.element_order(n)):
+        X, yr, _ = parity.synthetic_real(90 + 10 * e, 1, 300 + e)
+        y = yr.astype(complex) if i == j else 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0))
+        sets[(i, j)] = (X, y)
+        params[(i, j)] = [1.0, 0.75, 0.7, 0.05] if i == j else [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05]
+    kg = K.TrainingKernels(params, sets, True, True, True, api=gpu, num_pes=n)
+    ko = K.TrainingKernels(params, sets, True, True, True, api=oracle, num_pes=n)
+    E = [0.1, 0.2, 0.4]
+    assert abs(kg.calculate_population() - ko.calculate_population()) <= 1e-8 * abs(ko.calculate_population())
+    assert abs(kg.calculate_purity() - ko.calculate_purity()) <= 1e-6 * abs(ko.calculate_purity())
+    assert abs(kg.calculate_total_energy_average(E) - ko.calculate_total_energy_average(E)) <= 1e-8
+    assert np.allclose(kg.calculate_1st_order_average(), ko.calculate_1st_order_average(), rtol=1e-8)
+    pdg, pdo = kg.purity_derivative(), ko.purity_derivative()
+    assert len(pdg) == 3 * 4 + 3 * 8
+    assert np.abs(pdg - pdo).max() <= 1e-5 * np.abs(pdo).max()
+    assert np.abs(kg.population_derivative() - ko.population_derivative()).max() <= 1e-6 * np.abs(ko.population_derivative()).max()
+
+
+# ---- a15 / a18 / a19 on the HIP path against the oracle ---------------------------------------------------------------------------
+def two_state_case():
+    sets, extra, params = {}, {}, {}
+    for e, (i, j) in enumerate(K.element_order(2)):
+        X, yr, Xs = parity.synthetic_real(160 + 20 * e, 400, 500 + e)
+        cplx = i != j
+        ph = lambda P: np.exp(0.5j * (P[:, 0] + 10.0)) * 0.5 if cplx else 1.0
+        sets[(i, j)] = (X, yr * ph(X) + 0j)
+        Xe = X[np.arange(3 * len(X)) % len(X)] + np.random.default_rng(9 + e).normal(0, 0.4, size=(3 * len(X), 2))
+        re = np.exp(-0.5 * (((Xe[:, 0] + 10.0) / SX) ** 2 + ((Xe[:, 1] - P0) / SP) ** 2)) / (2 * np.pi * SX * SP)
+        extra[(i, j)] = (Xe, re * ph(Xe) + 0j)
+        params[(i, j)] = [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05] if cplx else [1.0, 0.75, 0.7, 0.05]
+    return sets, extra, params
+
+
+def test_training_kernels_aggregates_against_oracle(gpu, oracle):
+    """TrainingKernels (predict.cpp:290-559): every aggregate and its derivative packing, HIP vs oracle"""
+    sets, _, params = two_state_case()
+    kg = K.TrainingKernels(params, sets, True, True, True, api=gpu)
+    ko = K.TrainingKernels(params, sets, True, True, True, api=oracle)
+    E = [0.3, 0.7]
+    assert abs(kg.calculate_population() - ko.calculate_population()) <= 1e-8 * abs(ko.calculate_population())
+    assert abs(kg.calculate_purity() - ko.calculate_purity()) <= 1e-6 * abs(ko.calculate_purity())
+    assert abs(kg.calculate_total_energy_average(E) - ko.calculate_total_energy_average(E)) <= 1e-8
+    assert np.allclose(kg.calculate_1st_order_average(), ko.calculate_1st_order_average(), rtol=1e-8)
+    for f, args in (("population_derivative", ()), ("total_energy_derivative", (E,)), ("purity_derivative", ())):
+        a, b = getattr(kg, f)(*args), getattr(ko, f)(*args)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), f
+
+
+def test_full_and_diagonal_objectives_and_constraints_against_oracle(gpu, oracle):
+    """full_loose / diagonal_loose (opt.cpp:594-617, 844-870) and full_constraints / diagonal_constraints (:644-719, :879-929):
+    values and row-major gradients, HIP vs oracle, on one context and on a pool of three"""
+    sets, extra, params = two_state_case()
+    x = K.construct_combined_parameters(params)
+    pool = K.ApiPool(n=3)
+    try:
+        go = [0.0] * 16
+        vo = K.full_loose(x, go, (sets, extra), api=oracle)
+        for api in (gpu, pool):
+            gg = [0.0] * 16
+            vg = K.full_loose(x, gg, (sets, extra), api=api)
+            assert abs(vg - vo) <= 1e-6 * abs(vo)
+            assert np.abs(np.array(gg) - go).max() <= 1e-5 * np.abs(go).max()
+            assert abs(K.full_loose(x, [], (sets, extra), api=api) - vg) <= 1e-12 * abs(vg)
+        xd = params[(0, 0)] + params[(1, 1)]
+        gdo, gdg = [0.0] * 8, [0.0] * 8
+        vdo, vdg = K.diagonal_loose(xd, gdo, (sets, extra), api=oracle), K.diagonal_loose(xd, gdg, (sets, extra), api=gpu)
+        assert abs(vdg - vdo) <= 1e-6 * abs(vdo) and np.abs(np.array(gdg) - gdo).max() <= 1e-5 * np.abs(gdo).max()
+        cp = (sets, [0.3, 0.7], 0.45, 1.0)
+        ro, co = K.full_constraints(x, True, cp, api=oracle)
+        for api in (gpu, pool):
+            rg, cg = K.full_constraints(x, True, cp, api=api)
+            assert np.abs(np.array(rg) - ro).max() <= 1e-6 * max(1.0, np.abs(ro).max())
+            assert len(cg) == 48 and np.abs(np.array(cg) - co).max() <= 1e-5 * np.abs(co).max()
+        for m in (2, 3):
+            rdo, cdo = K.diagonal_constraints(m, xd, True, cp, api=oracle)
+            rdg, cdg = K.diagonal_constraints(m, xd, True, cp, api=gpu)
+            assert len(rdg) == m and len(cdg) == 8 * m
+            assert np.abs(np.array(rdg) - rdo).max() <= 1e-6 * max(1.0, np.abs(rdo).max())
+            assert np.abs(np.array(cdg) - cdo).max() <= 1e-5 * np.abs(cdo).max()
+        assert K.full_constraints(x, False, cp, api=gpu)[1] is None
+    finally:
+        pool.close()
+
+
+# ---- identities that depend on neither restatement, on the HIP path ----------------------------------------------------------------
+def test_loocv_identity_bruteforce_on_gpu(gpu):
+    """Error = sum (v_i / W_ii)^2 equals the squared leave-one-out residuals of N refits — every refit on the GPU"""
+    X, y, _ = parity.synthetic_real(33, 4, 5)
+    theta = [1.0, 0.9, 0.8, 0.1]
+    fit = gpu.real_fit(theta, X, y, c.CALC_ERROR)
+    s = fit.scalars["rescale_factor"]
+    total = 0.0
+    for i in range(len(X)):
+        keep = np.arange(len(X)) != i
+        sub = gpu.real_fit(theta, X[keep], y[keep], 0)
+        # the sub-fit rescales its own labels (s' = 10 / max|y'|): undo it to compare in the units of the full fit
+        mu = gpu.real_predict(sub, X[i:i + 1], want=("prediction",))["prediction"][0] / sub.scalars["rescale_factor"] * s
+        total += (mu - y[i] * s) ** 2
+    assert abs(total - fit.scalars["error"]) <= 1e-8 * total
+
+
+def test_error_gradients_match_finite_differences_on_gpu(gpu):
+    """LOOCV error derivative (kernel.cpp:381-400; complex_kernel.cpp:444-474) vs central differences of the error itself"""
+    X, yr, _ = parity.synthetic_real(60, 4, 6)
+    theta = np.array([1.1, 0.9, 0.8, 0.15])
+    g = gpu.real_fit(theta, X, yr, c.CALC_ERROR | c.CALC_DERIVATIVE).scalars["error_derivative"]
+    for ip in range(4):
+        h = 1e-6 * theta[ip]
+        tp, tm = theta.copy(), theta.copy()
+        tp[ip] += h
+        tm[ip] -= h
+        fd = (gpu.real_fit(tp, X, yr, 1).scalars["error"] - gpu.real_fit(tm, X, yr, 1).scalars["error"]) / (2 * h)
+        assert abs(fd - g[ip]) <= 1e-5 * max(1.0, abs(fd)), (ip, fd, g[ip])
+    y = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0))
+    thc = np.array([1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.2])  # sigma = 1: the reference's derivative quirks vanish there
+    gc = gpu.complex_fit(thc, X, y, c.CALC_ERROR | c.CALC_DERIVATIVE).scalars["error_derivative"]
+    for ip in (1, 2, 3, 4, 5, 6):
+        h = 1e-6 * thc[ip]
+        tp, tm = thc.copy(), thc.copy()
+        tp[ip] += h
+        tm[ip] -= h
+        fd = (gpu.complex_fit(tp, X, y, 1).scalars["error"] - gpu.complex_fit(tm, X, y, 1).scalars["error"]) / (2 * h)
+        assert abs(fd - gc[ip]) <= 1e-5 * max(1.0, abs(fd)), (ip, fd, gc[ip])
+
+
+def test_purity_is_grid_quadrature_of_the_squared_mean(gpu):
+    """Purity = (2 pi hbar)^D integral of rho^2 (kernel.cpp:313-335) == (2 pi) * grid quadrature of the squared uncut mean"""
+    X, y, _ = parity.synthetic_real(60, 4, 7)
+    theta = [1.0, 0.7086, 0.7056, 0.05]
+    fit = gpu.real_fit(theta, X, y, c.CALC_AVERAGE)
+    G = 400
+    xs, ps = np.linspace(-18, -2, G), np.linspace(6, 22, G)
+    gx, gp = np.meshgrid(xs, ps, indexing="ij")
+    p = gpu.real_predict(fit, np.stack([gx.ravel(), gp.ravel()], 1), want=("prediction",))
+    s = fit.scalars["rescale_factor"]
+    quad = 2 * np.pi * ((p["prediction"] / s) ** 2).sum() * (xs[1] - xs[0]) * (ps[1] - ps[0])
+    assert abs(quad - fit.scalars["purity"]) <= 1e-6 * abs(fit.scalars["purity"])
+
+
+# ---- the reference's one analytic known-answer scenario ---------------------------------------------------------------------------
+def test_continue_test_scenario_known_answer(gpu, oracle):
+    """test/continue_test.cpp:37-44, 74-106, 456-520: fit the analytic target exp(-(((x - x0)/sigma_x)^2 + (p - p0/sigma_p)^2)/2)
+    (the `p - p0/sigma_p` precedence quirk of :76 kept: centre (x0, p0/sigma_p), widths (sigma_x, 1)) from N = 200 Metropolis
+    samples, hyper-parameters by minimising the NLML (gple_nlml value + gradient; the reference's half-gradient on the two
+    kernel weights, test/gpr.cpp:425,432, is kept, so only the value drives the search here), predict on the 241 x 241 grid
+    of :43-44 and compare with the exact function: MSE bound, and the HIP mean against the oracle's."""
+    from scipy.optimize import minimize
+    NPoint, NStep, NGrid = 200, 500, 241
+    xmin, xmax, pmin, pmax, dxmax, dpmax = -15.0, 15.0, -11.0208, 39.2447, 0.125, 0.20945
+    func = lambda x, p: np.exp(-(((x - X0) / SX) ** 2 + (p - P0 / SP) ** 2) / 2.0)
+    rng = np.random.Generator(np.random.PCG64(20240607))  # the reference seeds from the clock (:80): any seed is a valid run
+    x, p = rng.uniform(xmin, xmax, NPoint), rng.uniform(pmin, pmax, NPoint)
+    w = func(x, p)
+    for _ in range(NStep):  # generate_training_set (:84-106), the NPoint chains advanced together
+        xn, pn = x + rng.uniform(-dxmax, dxmax, NPoint), p + rng.uniform(-dpmax, dpmax, NPoint)
+        wn = func(xn, pn)
+        u = rng.uniform(0, 1, NPoint)
+        ok = (xn >= xmin) & (xn <= xmax) & (pn >= pmin) & (pn <= pmax) & ~((wn < w) & (wn / np.maximum(w, 1e-300) < u))
+        x, p, w = np.where(ok, xn, x), np.where(ok, pn, p), np.where(ok, wn, w)
+    X = np.stack([x, p], axis=1)
+    lb = np.array([1e-8, 1e-4, 1.0 / (xmax - xmin), 1.0 / (pmax - pmin)])     # set_initial_value (:113-163)
+    ub = np.array([1e-5, 1.0, 1e3, 1e3])
+    x_init = np.array([1e-8, 1.0, 1.0 / SX, 1.0 / SP])
+    gx, gp = np.meshgrid(np.linspace(xmin, xmax, NGrid), np.linspace(pmin, pmax, NGrid), indexing="ij")
+    grid = np.stack([gx.ravel(), gp.ravel()], axis=1)
+    real = func(grid[:, 0], grid[:, 1])
+    # (i) the initial hyper-parameters of :113-163 (weights = 1 / sigma): the GP reproduces the packet.  Bounds calibrated on the
+    # oracle over three seeds (MSE 8e-11 .. 4e-8, error at the packet <= 4.3e-3).
+    sim0 = gpu.nlml_predict(x_init, X, w, grid)
+    assert ((sim0 - real) ** 2).mean() <= 1e-6
+    assert np.abs(sim0 - real).max() <= 2e-2
+    assert np.abs(sim0 - oracle.nlml_predict(x_init, X, w, grid)).max() <= 1e-7
+    # (ii) after the reference's NLML minimisation (non-gradient stage, :475-487): the likelihood prefers longer lengths (two
+    # thirds of the Metropolis samples sit where the target is 0), which keeps the packet (error <= 2e-2 where real > 0.5) but
+    # extrapolates worse away from the samples (oracle: MSE 1.1e-3 .. 3.2e-3) — the scenario's "answer" is the packet itself.
+    res = minimize(lambda h: gpu.nlml(np.clip(h, lb, ub), X, w, want_grad=False)[0], x_init, method="Nelder-Mead",
+                   options={"xatol": 1e-6, "fatol": 1e-9, "maxiter": 400})
+    hyp = np.clip(res.x, lb, ub)
+    v0, v1 = gpu.nlml(x_init, X, w, want_grad=False)[0], gpu.nlml(hyp, X, w, want_grad=False)[0]
+    assert v1 < v0 - 100.0  # oracle: -188 -> -542
+    assert abs(v1 - oracle.nlml(hyp, X, w, want_grad=False)[0]) <= 1e-7 * abs(v1)
+    sim = gpu.nlml_predict(hyp, X, w, grid)
+    assert ((sim - real) ** 2).mean() <= 1e-2
+    assert np.abs(sim - real)[real > 0.5].max() <= 2e-2
+    assert np.abs(sim - oracle.nlml_predict(hyp, X, w, grid)).max() <= 1e-6 * max(1.0, np.abs(sim).max())
+
+
+# ---- lifetime at the C-ABI (use-after-free of a destroyed context) -----------------------------------------------------
+def test_handles_survive_their_context(gpu):
+    """create -> fit -> ctx_destroy -> getters / release: a status, not a crash (include/gple.h, lifetime rule)"""
+    import ctypes as C
+    import gaussian_process_liouville_equation_amd as pkg
+    api = pkg.open_api(0)
+    X, y, Xs = parity.synthetic_real(120, 50, 3)
+    fit = api.real_fit(THETA_R, X, y, 3, defer_scalars=True)
+    obj = api.objective(X, y.astype(complex), Xs, np.zeros(len(Xs), complex))
+    ctx = api.ctx
+    lib = api.lib
+    assert lib.gple_ctx_destroy(ctx) == 0          # the fit and the objective keep the context alive
+    api.ctx = None
+    assert lib.gple_ctx_destroy(ctx) == 4           # GPLE_ERR_STATE: already destroyed
+    sc = c.RealFitScalars()
+    assert lib.gple_real_fit_get_scalars(fit.handle, C.byref(sc)) == 0 and np.isfinite(sc.error)  # deferred scalars still arrive
+    ref = gpu.real_fit(THETA_R, X, y, 3).scalars
+    assert sc.error == ref["error"] and sc.population == ref["population"]
+    buf = np.empty(len(X))
+    assert lib.gple_real_fit_get(fit.handle, c.R_INVLBL, 0, buf.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    ps = c.PredictScalars()
+    out = np.empty(len(Xs))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    Xs_c = np.ascontiguousarray(Xs)
+    assert lib.gple_real_predict(ctx, fit.handle, dp(Xs_c), len(Xs), 0, None, dp(out), None, None, C.byref(ps)) == 4  # closed context
+    val = C.c_double()
+    th = np.array(THETA_R)
+    assert lib.gple_objective_eval(obj.handle, dp(th), 4, C.cast(C.byref(val), C.POINTER(C.c_double)), None) == 4
+    obj.release()
+    fit.release()  # the last handle frees the context
