@@ -153,7 +153,11 @@ namespace gple
 		// wave 1 owns 64 panel rows.  Per column: wave 0 takes the pivot by readlane and publishes the scaled column with
 		// 1/L_kk next to it; after the barrier every lane scales its own entry and applies the rank-1 update to its row.
 		// A points at block (j0, j0); m = rows from j0 to the end of the matrix (multiple of 64).
-		__global__ void __launch_bounds__(PANEL_THREADS) potrf_panel_kernel(double* __restrict__ A, long lda, int m, int* __restrict__ info, int j0)
+		// The factored diagonal block goes to D (ldd), NOT back into A: every workgroup reads A's diagonal block when it starts,
+		// and a workgroup that is dispatched late (other streams keeping CUs busy) must still find it unfactored.  Writing it in
+		// place was a race between workgroup 0's stores and late workgroups' loads — invisible on an otherwise idle GPU.
+		__global__ void __launch_bounds__(PANEL_THREADS) potrf_panel_kernel(double* __restrict__ A, long lda, int m, int* __restrict__ info, int j0,
+			double* __restrict__ D, long ldd)
 		{
 			__shared__ __attribute__((aligned(16))) double col[2][NB + 2];
 			__shared__ double dump[PANEL_THREADS];
@@ -170,20 +174,23 @@ namespace gple
 			if (first_bad != 0 && threadIdx.x == 0 && blockIdx.x == 0) atomicCAS(info, 0, j0 + first_bad); // info starts at 0
 			if (valid && (!diag || blockIdx.x == 0))
 			{
-				double* __restrict__ dst = A + row;
+				double* __restrict__ dst = diag ? D + row : A + row;
+				const long ld = diag ? ldd : lda;
 #pragma unroll
-				for (int j = 0; j < NB; ++j) dst[static_cast<long>(j) * lda] = a[j];
+				for (int j = 0; j < NB; ++j) dst[static_cast<long>(j) * ld] = a[j];
 			}
 		}
 
 		// Tinv_b = L_b^-1 for every 64 x 64 diagonal block b of the factor (one wave per block, all blocks in one launch):
 		// lane j owns column j of the inverse and runs its own forward substitution; row r of L is an LDS broadcast.
-		__global__ void __launch_bounds__(64) trinv_diag_kernel(const double* __restrict__ L, long ldl, double* __restrict__ T, long ldt)
+		// Called in place (L == T: the panel kernel leaves L_b in T's diagonal blocks): a block is read completely into LDS
+		// before the barrier and written after it, by its own workgroup only.
+		__global__ void __launch_bounds__(64) trinv_diag_kernel(const double* L, long ldl, double* T, long ldt)
 		{
 			__shared__ __attribute__((aligned(16))) double Ls[NB * LR];
 			const long off = static_cast<long>(blockIdx.x) * NB;
-			const double* __restrict__ Lb = L + off + off * ldl;
-			double* __restrict__ Tb = T + off + off * ldt;
+			const double* Lb = L + off + off * ldl;
+			double* Tb = T + off + off * ldt;
 			const int i = threadIdx.x;
 #pragma unroll
 			for (int j = 0; j < NB; ++j)
@@ -238,7 +245,8 @@ namespace gple
 			const int m = n - j0; // rows of the panel including the diagonal block
 			const int below = m - NB;
 			const int nwg = below > 0 ? (below + PANEL_ROWS - 1) / PANEL_ROWS : 1;
-			hipLaunchKernelGGL(potrf_panel_kernel, dim3(nwg), dim3(PANEL_THREADS), 0, s, A + j0 + static_cast<long>(j0) * lda, lda, m, info, j0);
+			hipLaunchKernelGGL(potrf_panel_kernel, dim3(nwg), dim3(PANEL_THREADS), 0, s, A + j0 + static_cast<long>(j0) * lda, lda, m, info, j0,
+				T + j0 + static_cast<long>(j0) * ldt, ldt);
 			if (below <= 0) break;
 			// trailing update: A22 -= P P^T (lower tiles)
 			double* P = A + (j0 + NB) + static_cast<long>(j0) * lda;
@@ -250,7 +258,7 @@ namespace gple
 			if (e != hipSuccess) return e;
 		}
 		// the 64 x 64 inverses are only the leaves of the merge tree: one batched launch, off the factorisation's critical path
-		hipLaunchKernelGGL(trinv_diag_kernel, dim3(n / NB), dim3(64), 0, s, A, lda, T, ldt);
+		hipLaunchKernelGGL(trinv_diag_kernel, dim3(n / NB), dim3(64), 0, s, T, ldt, T, ldt);
 		return hipGetLastError();
 	}
 

@@ -133,9 +133,11 @@ namespace gple
 	int gemm_pick_tile(long m, long n, long batch, bool triangular);
 
 	// ---- dense factorisation drivers (gple_chol.hip) -------------------------------------------------------
-	// In-place lower Cholesky of the n x n (n multiple of CHOL_NB) column-major matrix A; the strictly upper part
-	// is zeroed. diag_inv receives inv(L_jj) of every CHOL_NB diagonal block *inside* T (n x n, ldt), i.e. the
-	// diagonal blocks of T = L^-1. info (device int): 0 or 1 + index of the first non-positive pivot.
+	// Lower Cholesky of the n x n (n multiple of CHOL_NB) column-major matrix A: the blocks strictly below the block
+	// diagonal are overwritten by the factor; the CHOL_NB diagonal blocks of A are left untouched (their factors pass through
+	// T's diagonal blocks, see potrf_panel_kernel) and the upper part is not referenced.  On return T (n x n, ldt) holds
+	// inv(L_jj) in every diagonal block, i.e. the diagonal blocks of T = L^-1.  info (device int): 0 or 1 + index of the
+	// first non-positive pivot.
 	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info);
 	// Completes T = L^-1 (lower) given its diagonal blocks; work: at least n*n/4 doubles.
 	hipError_t trtri_lower_from_diag(hipStream_t s, const double* L, long ldl, double* T, long ldt, int n, double* work);
