@@ -50,6 +50,11 @@ class ComplexFitScalars(C.Structure):
     ]
 
 
+class Element(C.Structure):
+    """gple_element: the fit of one density-matrix element (exactly one of the two set, or neither)"""
+    _fields_ = [("real", C.c_void_p), ("cplx", C.c_void_p)]
+
+
 class PredictScalars(C.Structure):
     _fields_ = [("error", C.c_double), ("error_derivative", C.c_double * 8)]
 
@@ -89,7 +94,7 @@ def _cplx(y):
 # every symbol include/gple.h declares (checked by tests/test_capi_symbols.py)
 GPLE_SYMBOLS = [
     "ctx_create", "ctx_destroy", "ctx_synchronize", "ctx_trim", "status_string", "ctx_last_error", "ctx_enable_timing", "ctx_get_timing",
-    "real_gram", "cutoff_factor",
+    "real_gram", "complex_gram", "cutoff_factor", "predict_batch",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
     "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "nlml", "nlml_predict",
@@ -191,6 +196,7 @@ class Api:
         sz, vp, ci = C.c_size_t, C.c_void_p, C.c_int
         sig = {
             "real_gram": ctx + [_dp, _dp, sz, _dp, sz, ci] + fl + [_dp, _dp],
+            "complex_gram": ctx + [_dp, _dp, sz, _dp, sz, ci] + fl + [_dp, _dp, _dp, _dp],
             "cutoff_factor": ctx + [_dp, ci, _dp, sz] + fl + [_dp],
             "real_fit_create": ctx + [_dp, _dp, _dp, ci, sz, C.c_uint, C.POINTER(RealFitScalars), C.POINTER(vp)],
             "real_fit_release": [vp],
@@ -211,6 +217,8 @@ class Api:
             for kind, st in (("real", RealFitScalars), ("complex", ComplexFitScalars)):
                 f = self._fn(f"{kind}_fit_get_scalars")
                 f.argtypes, f.restype = [vp, C.POINTER(st)], C.c_int
+            self.lib.gple_predict_batch.argtypes = [vp, C.POINTER(Element), sz, _dp, C.POINTER(ci), sz, _dp]
+            self.lib.gple_predict_batch.restype = C.c_int
             self.lib.gple_objective_create.argtypes = [vp, _dp, _dp, sz, _dp, _dp, sz, C.POINTER(vp)]
             self.lib.gple_objective_eval.argtypes = [vp, _dp, sz, _dp, _dp]
             self.lib.gple_objective_release.argtypes = [vp]
@@ -280,6 +288,32 @@ class Api:
         if derivative:
             return K, dK.reshape(4, Cc, R).transpose(0, 2, 1)
         return K
+
+    def complex_gram(self, theta, left, right, same_features=False, derivative=False):
+        """ComplexKernelBase: (K, Kt) or (K, Kt, dK[8], dKt[8]), R x C arrays"""
+        theta, left, right = _f64(theta), _points(left), _points(right)
+        R, Cc = len(left), len(right)
+        K, Kt = np.empty(R * Cc), np.empty(2 * R * Cc)
+        dK = np.empty(8 * R * Cc) if derivative else None
+        dKt = np.empty(16 * R * Cc) if derivative else None
+        self._check(self._fn("complex_gram")(*self._c(), _ptr(theta), _ptr(left), R, _ptr(right), Cc, int(same_features),
+                                             *self._fl(), _ptr(K), _ptr(Kt), _ptr(dK), _ptr(dKt)))
+        K, Kt = K.reshape(Cc, R).T, Kt.view(np.complex128).reshape(Cc, R).T
+        if derivative:
+            return K, Kt, dK.reshape(8, Cc, R).transpose(0, 2, 1), dKt.view(np.complex128).reshape(8, Cc, R).transpose(0, 2, 1)
+        return K, Kt
+
+    def predict_batch(self, elements, points, element_of_request):
+        """gple_predict_batch: elements = list of _Fit or None; points (n,2); element_of_request (n,) ints -> complex (n,)"""
+        arr = (Element * max(1, len(elements)))()
+        for i, f in enumerate(elements):
+            if f is not None:
+                setattr(arr[i], "real" if f.kind == "real" else "cplx", f.handle.value)
+        pts = _points(points)
+        idx = np.ascontiguousarray(element_of_request, dtype=np.int32)
+        out = np.empty(2 * len(pts))
+        self._check(self.lib.gple_predict_batch(self.ctx, arr, len(elements), _ptr(pts), idx.ctypes.data_as(C.POINTER(C.c_int)), len(pts), _ptr(out)))
+        return out.view(np.complex128)
 
     def cutoff_factor(self, prediction, variance):
         is_c = np.iscomplexobj(prediction)

@@ -774,6 +774,41 @@ extern "C"
 		return GPLE_OK;
 	}
 
+	// ---- ComplexKernelBase ---------------------------------------------------------------------------------------
+	int gple_complex_gram(gple_ctx* ctx, const double theta[8], const double* left, size_t R, const double* right, size_t C, int same_features,
+		unsigned flags, double* K, double* Kt, double* dK, double* dKt)
+	{
+		if (!ctx || !theta || !K || (R && !left) || (C && !right)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		if (R == 0 || C == 0) return GPLE_OK;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		if (flags & GPLE_IO_DEVICE)
+		{
+			GPLE_HIP(ctx, launch_complex_gram(st, theta, left, (int)R, right, (int)C, same_features, K, Kt, dK, dKt));
+			return GPLE_OK;
+		}
+		const size_t rc = R * C;
+		Scratch l(ctx), r(ctx), k(ctx), kt(ctx), dk(ctx), dkt(ctx);
+		GPLE_HIP(ctx, l.get(2 * R));
+		GPLE_HIP(ctx, r.get(2 * C));
+		GPLE_HIP(ctx, k.get(rc));
+		if (Kt) GPLE_HIP(ctx, kt.get(2 * rc));
+		if (dK) GPLE_HIP(ctx, dk.get(8 * rc));
+		if (dKt) GPLE_HIP(ctx, dkt.get(16 * rc));
+		GPLE_HIP(ctx, copy_in(st, l.p, left, 2 * R, false));
+		GPLE_HIP(ctx, copy_in(st, r.p, right, 2 * C, false));
+		GPLE_HIP(ctx, launch_complex_gram(st, theta, l.p, (int)R, r.p, (int)C, same_features, k.p, Kt ? kt.p : nullptr, dK ? dk.p : nullptr,
+						  dKt ? dkt.p : nullptr));
+		GPLE_HIP(ctx, copy_out(st, K, k.p, rc, false));
+		if (Kt) GPLE_HIP(ctx, copy_out(st, Kt, kt.p, 2 * rc, false));
+		if (dK) GPLE_HIP(ctx, copy_out(st, dK, dk.p, 8 * rc, false));
+		if (dKt) GPLE_HIP(ctx, copy_out(st, dKt, dkt.p, 16 * rc, false));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		return GPLE_OK;
+	}
+
 	int gple_cutoff_factor(gple_ctx* ctx, const double* prediction, int is_complex, const double* variance, size_t M, unsigned flags,
 		double* factor)
 	{
@@ -1346,6 +1381,50 @@ extern "C"
 		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
 		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
+	}
+
+	// ---- batched point-predict (N1): gather -> one predict per element -> scatter ------------------------------------
+	int gple_predict_batch(gple_ctx* ctx, const gple_element* elements, size_t n_elements, const double* points, const int* element_of_request,
+		size_t n_req, double* out)
+	{
+		if (!ctx || (n_elements && !elements) || (n_req && (!points || !element_of_request || !out))) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		std::vector<std::vector<size_t>> by_element(n_elements);
+		for (size_t r = 0; r < n_req; ++r)
+		{
+			const int e = element_of_request[r];
+			if (e < 0 || static_cast<size_t>(e) >= n_elements) return GPLE_ERR_BAD_ARG;
+			by_element[e].push_back(r);
+		}
+		std::vector<double> pts, cut;
+		for (size_t e = 0; e < n_elements; ++e)
+		{
+			const std::vector<size_t>& req = by_element[e];
+			if (req.empty()) continue;
+			const gple_element& el = elements[e];
+			if (el.real && el.cplx) return GPLE_ERR_BAD_ARG;
+			if (!el.real && !el.cplx) // element without a kernel: 0 (main.cpp:86-88, 97-99)
+			{
+				for (size_t r : req) out[2 * r] = out[2 * r + 1] = 0.0;
+				continue;
+			}
+			const size_t m = req.size();
+			pts.resize(2 * m);
+			for (size_t q = 0; q < m; ++q) pts[2 * q] = points[2 * req[q]], pts[2 * q + 1] = points[2 * req[q] + 1];
+			if (el.real)
+			{
+				cut.resize(m);
+				GPLE_TRY(predict_common(ctx, el.real, pts.data(), m, 0u, nullptr, nullptr, nullptr, cut.data(), nullptr));
+				for (size_t q = 0; q < m; ++q) out[2 * req[q]] = cut[q], out[2 * req[q] + 1] = 0.0;
+			}
+			else
+			{
+				cut.resize(2 * m);
+				GPLE_TRY(predict_common(ctx, el.cplx, pts.data(), m, 0u, nullptr, nullptr, nullptr, cut.data(), nullptr));
+				for (size_t q = 0; q < m; ++q) out[2 * req[q]] = cut[2 * q], out[2 * req[q] + 1] = cut[2 * q + 1];
+			}
+		}
+		return GPLE_OK;
 	}
 
 	// loose_function (opt.cpp:441-482).  io = 0: host pointers; io = GPLE_IO_DEVICE: everything but x / value / grad is resident

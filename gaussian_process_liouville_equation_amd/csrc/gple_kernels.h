@@ -92,6 +92,9 @@ namespace gple
 	// p.amp = sf*sf, p.n2 = sn*sn; sf and sn are passed too because the derivative formulas use them unsquared.
 	hipError_t launch_gram_rect(hipStream_t s, const double* L, int R, const double* Rt, int C, int same, SEParam p, double sf, double sn,
 		double* K, double* dK);
+	// ComplexKernelBase (gple_cgram.hip): K (R x C), K~ (R x C (re,im) pairs, nullable), dK (8 x R x C, nullable), dK~ (8 x R x C pairs, nullable)
+	hipError_t launch_complex_gram(hipStream_t s, const double theta[8], const double* L, int R, const double* Rt, int C, int same, double* K,
+		double* Kt, double* dK, double* dKt);
 	hipError_t launch_sum(hipStream_t s, const double* part, int n, double* out);
 	hipError_t launch_cutoff(hipStream_t s, const double* pred, int is_complex, const double* var, int M, double* factor);
 

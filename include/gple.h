@@ -143,6 +143,13 @@ int gple_ctx_get_timing(gple_ctx* ctx, gple_timer which, double* last_ms, double
 int gple_real_gram(gple_ctx* ctx, const double theta[4], const double* left, size_t R, const double* right, size_t C,
 	int same_features, unsigned flags, double* K, double* dK);
 
+/* ---- ComplexKernelBase (complex_kernel.h:14-145, complex_kernel.cpp:20-200) ------------------------ */
+/* theta = (s, sR, lRx, lRp, sI, lIx, lIp, sn).  K = s^2 (K_R + K_I + sn^2 delta) is R x C real; Kt (nullable) = s^2 (K_R - K_I +
+ * 2i K_C), R x C (re,im) pairs; dK (nullable) receives the 8 derivative matrices of K (8*R*C doubles, get_derivative()), dKt
+ * (nullable) the 8 of Kt (16*R*C doubles, get_pseudo_derivative()).  same_features as in gple_real_gram. */
+int gple_complex_gram(gple_ctx* ctx, const double theta[8], const double* left, size_t R, const double* right, size_t C,
+	int same_features, unsigned flags, double* K, double* Kt, double* dK, double* dKt);
+
 /* cutoff_factor<T> (kernel.h:301-332). prediction has M (real) or 2M (complex) doubles. */
 int gple_cutoff_factor(gple_ctx* ctx, const double* prediction, int is_complex, const double* variance, size_t M,
 	unsigned flags, double* factor);
@@ -203,6 +210,22 @@ int gple_objective_create(gple_ctx* ctx, const double* X, const double* y, size_
 /* loose_function(x, grad, params): n = 4 (real element) or 8 (complex element); grad may be NULL. */
 int gple_objective_eval(gple_objective* objective, const double* x, size_t n, double* value, double* grad);
 int gple_objective_release(gple_objective* objective);
+
+/* ---- batched point-predict ------------------------------------------------------------------ */
+/* The reference evaluates its DistributionFunction (stdafx.h:155) one phase-space point at a time: main.cpp:75-101 constructs a
+ * Predictive*Kernel per call, evolve.cpp:298 asks for 8 points per sample, mc.cpp:158-172 for one per Metropolis step.  This entry
+ * takes all requests of a tick at once: request r wants the cut-off prediction (get_cutoff_prediction().value(), main.cpp:83,94)
+ * of element element_of_request[r] at point points[2r .. 2r+1].  elements[e] names the fit of density-matrix element e: exactly one
+ * of real / cplx is set, or neither for an element without a kernel (result 0, main.cpp:86-88).  One predict per element that
+ * has requests (gather -> predict -> scatter); out receives n_req (re,im) pairs (imaginary part 0 for real elements).
+ * Thread-safe; host pointers only. */
+typedef struct gple_element
+{
+	const gple_real_fit* real;
+	const gple_complex_fit* cplx;
+} gple_element;
+int gple_predict_batch(gple_ctx* ctx, const gple_element* elements, size_t n_elements, const double* points, const int* element_of_request,
+	size_t n_req, double* out);
 
 /* ---- negative_log_marginal_likelihood / predict (test/gpr.cpp:499-532, 654-706) -------------------- */
 /* Kernel = w_d^2 * Diag + w_g^2 * GaussianARD(weights), x = (w_d, w_g, a_x, a_p) with `a` the diagonal ARD

@@ -1176,6 +1176,25 @@ extern "C"
 		return GPLE_OK;
 	}
 
+	// ComplexKernelBase as a whole (complex_kernel.cpp:20-200): K, K~ and the 8 + 8 derivative matrices
+	int oracle_complex_gram(const double theta[8], const double* left, size_t R, const double* right, size_t C, int same_features, double* K,
+		double* Kt, double* dK, double* dKt)
+	{
+		if (!theta || !left || !right || !K) return GPLE_ERR_BAD_ARG;
+		const ComplexKernelBase kb(unpack_complex(theta), left, R, right, C, same_features != 0, dK != nullptr || dKt != nullptr);
+		std::copy(kb.K.a.begin(), kb.K.a.end(), K);
+		const size_t rc = R * C;
+		if (Kt)
+			for (size_t i = 0; i < rc; i++) Kt[2 * i] = kb.Kt.a[i].real(), Kt[2 * i + 1] = kb.Kt.a[i].imag();
+		for (int ip = 0; ip < 8; ip++)
+		{
+			if (dK) std::copy(kb.dK[ip].a.begin(), kb.dK[ip].a.end(), dK + ip * rc);
+			if (dKt)
+				for (size_t i = 0; i < rc; i++) dKt[2 * (ip * rc + i)] = kb.dKt[ip].a[i].real(), dKt[2 * (ip * rc + i) + 1] = kb.dKt[ip].a[i].imag();
+		}
+		return GPLE_OK;
+	}
+
 	int oracle_cutoff_factor(const double* prediction, int is_complex, const double* variance, size_t M, double* factor)
 	{
 		if (!prediction || !variance || !factor) return GPLE_ERR_BAD_ARG;

@@ -27,6 +27,8 @@ typedef struct oracle_complex_fit oracle_complex_fit;
 
 int oracle_real_gram(const double theta[4], const double* left, size_t R, const double* right, size_t C,
 	int same_features, double* K, double* dK);
+int oracle_complex_gram(const double theta[8], const double* left, size_t R, const double* right, size_t C, int same_features,
+	double* K, double* Kt, double* dK, double* dKt);
 int oracle_cutoff_factor(const double* prediction, int is_complex, const double* variance, size_t M, double* factor);
 
 int oracle_real_fit_create(const double theta[4], const double* X, const double* y, int y_is_complex, size_t N,

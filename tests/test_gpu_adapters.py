@@ -1,5 +1,6 @@
-"""GPU: the header-only C++ adapters (host/kernel.h, complex_kernel.h, predict.h — the reference's class names and
-signatures on top of the C-ABI) give the same numbers as the Python path.  The driver is built by __graft_entry__.build()."""
+"""GPU: the header-only C++ adapters (host/kernel.h, complex_kernel.h, predict.h — the reference's class names and signatures
+on top of the C-ABI), driven by tests/cpp/dropin_callers.cpp through the reference's own call patterns, against the CPU
+oracle evaluated through the Python mirror on the same inputs (the driver's inputs are regenerated here bit for bit)."""
 import os
 import subprocess
 
@@ -7,45 +8,141 @@ import numpy as np
 import pytest
 
 from gaussian_process_liouville_equation_amd import kernels as K
-from tests import parity
 from tests.conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
 
-def test_cpp_adapters_match_python_path(gpu, tmp_path):
-    exe = os.path.join(ROOT, "tests", "cpp", "adapter_driver")
+def driver_inputs(N):
+    """the LCG of dropin_callers.cpp main(): density and extra points of elements (0,0) and (1,0); (1,1) stays empty"""
+    state = 12345
+
+    def uni():
+        nonlocal state
+        state = (state * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        return (state >> 11) * (1.0 / 9007199254740992.0)
+
+    def sample(n, cplx):
+        r = np.empty((n, 2))
+        rho = np.empty(n, dtype=complex)
+        for i in range(n):
+            r[i, 0] = -10.0 + 2.4 * (uni() - 0.5)
+            r[i, 1] = 14.112 + 2.4 * (uni() - 0.5)
+            v = np.exp(-0.5 * (((r[i, 0] + 10.0) / 0.7086) ** 2 + ((r[i, 1] - 14.112) / 0.7056) ** 2)) / (2.0 * np.pi * 0.7086 * 0.7056)
+            rho[i] = 0.5 * v * np.exp(0.5j * (r[i, 0] + 10.0)) if cplx else v
+        return r, rho
+
+    dens, extra = {}, {}
+    for (i, j) in K.element_order(2):
+        if (i, j) == (1, 1):
+            dens[(i, j)] = extra[(i, j)] = (np.zeros((0, 2)), np.zeros(0, complex))
+        else:
+            dens[(i, j)] = sample(N, i != j)
+            extra[(i, j)] = sample(2 * N, i != j)
+    return dens, extra
+
+
+def test_reference_call_patterns_through_the_adapters(gpu, oracle):
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_callers")
     if not os.path.exists(exe):
-        pytest.fail("tests/cpp/adapter_driver missing: run __graft_entry__.build()")
-    X, yr, Xs = parity.synthetic_real(150, 77, 51)
-    y = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0))
-    path = tmp_path / "in.txt"
-    with open(path, "w") as f:
-        f.write(f"{len(X)} {len(Xs)}\n")
-        for (a, b), z in zip(X, y):
-            f.write("%.17g %.17g %.17g %.17g\n" % (a, b, z.real, z.imag))
-        for a, b in Xs:
-            f.write("%.17g %.17g\n" % (a, b))
-    out = subprocess.run([exe, str(path)], check=True, capture_output=True, text=True, timeout=120).stdout
-    got = {l.split()[0]: np.array(list(map(float, l.split()[1:]))) for l in out.strip().splitlines()}
-    theta = [1.0, 0.7086, 0.7056, 1e-2]
-    ctheta = [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05]
-    k = K.TrainingKernel(theta, (X, y), True, True, True, api=gpu)
-    p = K.PredictiveKernel(Xs, k, False)
-    close = lambda a, b: np.allclose(a, b, rtol=1e-11, atol=1e-13)
-    assert close(got["real_error"], k.get_error()) and close(got["real_copy_error"], k.get_error())
-    assert close(got["real_population"], k.get_population()) and close(got["real_purity"], k.get_purity())
-    assert np.allclose(got["real_error_derivative"], k.get_error_derivative(), rtol=1e-9, atol=1e-9)
-    assert close(got["real_cut_sum"], p.get_cutoff_prediction().sum()) and close(got["real_var_sum"], p.get_variance().sum())
-    assert close(got["real_one_point"], p.get_cutoff_prediction()[0])
-    ck = K.TrainingComplexKernel(ctheta, (X, y), True, True, False, api=gpu)
-    cp = K.PredictiveComplexKernel(Xs, ck, False)
-    assert close(got["complex_error"], ck.get_error()) and close(got["complex_purity"], ck.get_purity())
-    assert close(got["complex_cut_abs_sum"], np.abs(cp.get_cutoff_prediction()).sum()) and close(got["complex_var_sum"], cp.get_variance().sum())
-    assert close(got["all_population"], k.get_population()) and close(got["all_purity"], k.get_purity() + 2 * ck.get_purity())
-    assert got["all_has_11"][0] == 0
-    ye = np.array([0.01 * (i % 7) for i in range(len(Xs))], dtype=complex)
-    grad = [0.0] * 4
-    val = K.loose_function(theta, grad, ((X, y), (Xs, ye)), api=gpu)
-    assert close(got["loose_value"], val) and close(got["loose_value_nograd"], val)
-    assert np.allclose(got["loose_grad"], grad, rtol=1e-9, atol=1e-9)
+        pytest.fail("tests/cpp/dropin_callers missing: run __graft_entry__.build()")
+    N = 60
+    out = subprocess.run([exe, str(N)], check=True, capture_output=True, text=True, timeout=180).stdout
+    got = {}
+    for line in out.strip().splitlines():
+        key, *vals = line.split()
+        got[key] = np.array([float(v) for v in vals]) if key != "phase_first" else vals
+    dens, extra = driver_inputs(N)
+    theta, ctheta = [1.0, 0.7086, 0.7056, 1e-2], [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05]
+    params = {(0, 0): theta, (1, 0): ctheta, (1, 1): theta}
+    ko = K.TrainingKernels(params, dens, True, True, False, api=oracle)  # main.cpp:74 on the oracle
+    close = lambda a, b, rt=1e-8: np.allclose(a, b, rtol=rt, atol=rt * 1e-3)
+    r0 = np.array([[-10.1, 14.3]])
+    p00 = K.PredictiveKernel(r0, ko(0), False).get_cutoff_prediction()[0]
+    p10 = K.PredictiveComplexKernel(r0, ko(1, 0), False).get_cutoff_prediction()[0]
+    # main.cpp:75-101 point-wise lambda, the batcher and its point-wise wrapper all agree with the oracle
+    for k in ("point_00", "batch_00"):
+        assert close(got[k], [p00, 0.0], 1e-7), k
+    for k in ("point_10", "batch_10", "pointwise_10"):
+        assert close(got[k], [p10.real, p10.imag], 1e-6), k
+    assert np.all(got["point_last"] == 0) and np.all(got["batch_last"] == 0)  # element without a kernel (main.cpp:86-88)
+    assert np.array_equal(got["point_00"], got["batch_00"]) and np.array_equal(got["point_10"], got["batch_10"])
+    assert close(got["all_population"], ko.calculate_population()) and close(got["all_purity"], ko.calculate_purity(), 1e-6)
+    assert close(got["all_energy"], ko.calculate_total_energy_average([0.1, 0.2]))
+    assert close(got["mean_r"], ko(0).get_1st_order_average() / ko(0).get_population())
+    assert close(got["population_0"], ko(0).get_population())
+    assert close(got["rescale"], [ko(0).get_rescale_factor(), ko(1, 0).get_rescale_factor()], 1e-13)
+    # opt.cpp:441-482: the static loose_function over the class adapters == the one-call form == the oracle
+    for name, x, e in (("real", theta, (0, 0)), ("complex", ctheta, (1, 0))):
+        go = [0.0] * len(x)
+        vo = K.loose_function(x, go, (dens[e], extra[e]), api=oracle)
+        v, v0, v1 = got[f"{name}_loose"]
+        assert close(v, vo, 1e-7) and close(v0, vo, 1e-7) and v1 == v
+        assert np.allclose(got[f"{name}_loose_grad"], go, rtol=1e-5, atol=1e-7 * np.abs(go).max())
+        assert np.array_equal(got[f"{name}_loose_grad"], got[f"{name}_loose_grad_onecall"])
+    assert close(got["reparam"], [np.log(1.1), np.log(0.05), 8.0], 1e-15)
+    # opt.cpp:644-719
+    ro, co = K.diagonal_constraints(3, theta + theta, True, (dens, [0.1, 0.2], 0.25, 1.0), api=oracle)
+    assert close(got["constraints"], ro, 1e-6)
+    assert len(got["constraints_grad"]) == 24 and np.allclose(got["constraints_grad"], co, rtol=1e-5, atol=1e-6 * np.abs(co).max())
+    ko0 = K.TrainingKernel(theta, dens[(0, 0)], False, False, False, api=oracle)
+    koc = K.TrainingComplexKernel(ctheta, dens[(1, 0)], False, False, False, api=oracle)
+    assert close(got["magnitude"], [ko0.get_magnitude(), koc.get_magnitude()])
+    # ComplexKernelBase: same matrices as the training kernel's getters, correlation magnitude of complex_kernel.cpp:144-157
+    assert np.all(got["ckb_vs_training"] <= 1e-14)
+    Ko, Kto, dKo, dKto = oracle.complex_gram(ctheta, dens[(1, 0)][0], dens[(1, 0)][0], True, True)
+    assert close(got["ckb_dkt_1_0"], [dKto[1][1, 0].real, dKto[1][1, 0].imag], 1e-12)
+    ss0, ss1 = 0.8 ** 2 + 0.7 ** 2, 0.7 ** 2 + 0.8 ** 2
+    assert close(got["ckb_corr_magnitude"], np.sqrt(1.1 * 0.9 * (2 * 0.8 * 0.7 / ss0) * (2 * 0.7 * 0.8 / ss1)), 1e-15)
+    assert got["phase_lines"][0] == 4  # output.cpp:204-222: two lines per populated element ((1,1) is skipped in the driver)
+    grid = np.stack([-11.0 + 0.2 * np.arange(12), 13.5 + 0.1 * np.arange(12)], axis=1)
+    assert close(float(got["phase_first"][0]), K.PredictiveKernel(grid, ko(0), False).get_cutoff_prediction()[0], 1e-5)
+
+
+def test_complex_kernel_base_against_oracle(gpu, oracle):
+    """ComplexKernelBase (complex_kernel.cpp:20-200): K, K~ and all 8 + 8 derivative matrices, training and test branch"""
+    from tests import parity
+    X, _, Xs = parity.synthetic_real(70, 33, 123)
+    Xs[5] = X[9]  # one coincident point: the exact-equality delta of the rectangular branch (kernel.cpp:26)
+    for theta in ([1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05], [1.4, 0.6, 0.5, 0.9, 1.3, 0.8, 0.4, 0.2]):
+        for (L, R, same) in ((X, X, True), (Xs, X, False)):
+            g = gpu.complex_gram(theta, L, R, same, True)
+            o = oracle.complex_gram(theta, L, R, same, True)
+            for a, b, name in zip(g, o, ("K", "Kt", "dK", "dKt")):
+                scale = max(np.abs(b).max(), 1e-300)
+                assert a.shape == b.shape and np.abs(a - b).max() <= 64 * parity.EPS * scale, (name, same)
+            assert gpu.complex_gram(theta, L, R, same)[0].shape == (len(L), len(R))
+    # consistency with the training kernel's own getters
+    fit = gpu.complex_fit(theta, X, np.ones(len(X), complex), 0)
+    from gaussian_process_liouville_equation_amd import _capi as c
+    K0, Kt0 = gpu.complex_gram(theta, X, X, True)
+    assert np.abs(fit.get(c.C_KERNEL) - K0).max() <= 8 * parity.EPS * np.abs(K0).max()
+    assert np.abs(fit.get(c.C_PSEUDO) - Kt0).max() <= 8 * parity.EPS * np.abs(Kt0).max()
+
+
+def test_predict_batch_against_pointwise_and_oracle(gpu, oracle):
+    """gple_predict_batch (N1): mixed requests over a real, a complex and an absent element == one-point predicts == oracle"""
+    from tests import parity
+    X, yr, Xs = parity.synthetic_real(180, 400, 321)
+    yc = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0))
+    th, thc = [1.0, 0.7086, 0.7056, 1e-2], [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05]
+    fr, fc = gpu.real_fit(th, X, yr, 0), gpu.complex_fit(thc, X, yc, 0)
+    rng = np.random.default_rng(4)
+    which = rng.integers(0, 3, len(Xs)).astype(np.int32)
+    out = gpu.predict_batch([fr, fc, None], Xs, which)
+    fo_r, fo_c = oracle.real_fit(th, X, yr, 0), oracle.complex_fit(thc, X, yc, 0)
+    ref_r, ref_c = oracle.real_predict(fo_r, Xs)["cutoff"], oracle.complex_predict(fo_c, Xs)["cutoff"]
+    scale = np.abs(ref_r).max()
+    assert np.abs(out[which == 0] - ref_r[which == 0]).max() <= 1e-9 * scale
+    assert np.abs(out[which == 1] - ref_c[which == 1]).max() <= 1e-8 * scale
+    assert np.all(out[which == 2] == 0)
+    # a batch equals the one-point calls the reference makes (main.cpp:83, 94), bit for bit per element path
+    for i in (0, 7, 123):
+        if which[i] == 0:
+            one = gpu.real_predict(fr, Xs[i:i + 1], want=("cutoff",))["cutoff"][0]
+        elif which[i] == 1:
+            one = gpu.complex_predict(fc, Xs[i:i + 1], want=("cutoff",))["cutoff"][0]
+        else:
+            one = 0.0
+        assert abs(out[i] - one) <= 1e-12 * scale
+    assert gpu.predict_batch([fr, fc, None], np.zeros((0, 2)), np.zeros(0, np.int32)).size == 0

@@ -151,3 +151,31 @@ def test_output_writers_layout(oracle):
     output.output_param(f, opt)
     lines = f.getvalue().split("\n")
     assert len(lines) == 3 * 3 + 2 and [len(x.split()) for x in lines[:9]] == [4, 4, 4, 8, 8, 8, 4, 4, 4]
+
+
+@pytest.mark.parametrize("num_pes", [2, 3])
+def test_cpp_adapters_compile_in_the_reference_include_order(num_pes):
+    """host/kernel.h, complex_kernel.h, predict.h behind a stdafx.h / storage.h with the reference's include guards and global
+    names (tests/cpp/ref_env, this image has no Eigen): the reference's call patterns (opt.cpp:74-232, 441-482, 622-719,
+    1179-1195; main.cpp:74-101; output.cpp:181-290) compile without redefinitions or ambiguities.  Syntax only: no GPU here."""
+    import os
+    import subprocess
+    from tests.conftest import ROOT
+    cmd = ["g++", "-std=c++20", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", f"-DGPLE_TEST_NUM_PES={num_pes}",
+           "-I" + os.path.join(ROOT, "tests", "cpp", "ref_env"), "-I" + os.path.join(ROOT, "gaussian_process_liouville_equation_amd", "host"),
+           os.path.join(ROOT, "tests", "cpp", "dropin_callers.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for header in ("kernel.h", "complex_kernel.h", "predict.h", "gple_host.h"):
+        text = open(os.path.join(ROOT, "gaussian_process_liouville_equation_amd", "host", header)).read()
+        assert "using namespace" not in text
+        for name in ("NumPES =", "NumOffDiagonalElements =", "Dim =", "PhaseDim =", "class QuantumStorage", "calculate_offdiagonal_index("):
+            assert name not in text, (header, name)  # stdafx.h:107-155 / storage.h stay the reference's
+
+
+def test_oracle_complex_kernel_base_against_fixture(oracle):
+    """oracle_complex_gram (ComplexKernelBase as a whole) against the 50-digit fixtures' K and K~"""
+    for name, _ in parity.COMPLEX_FIXTURES:
+        g = load_golden(name)
+        Ko, Kto = oracle.complex_gram(g["theta"], g["X"], g["X"], True)
+        assert parity.rel(Ko, g["K"]) <= 8 * parity.EPS and parity.rel(Kto, g["Kt"]) <= 8 * parity.EPS
