@@ -97,7 +97,7 @@ GPLE_SYMBOLS = [
     "real_gram", "complex_gram", "cutoff_factor", "predict_batch",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
-    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "nlml", "nlml_predict",
+    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
 ]
 
 
@@ -209,6 +209,8 @@ class Api:
             "loose_function": ctx + [_dp, sz, _dp, _dp, sz, _dp, _dp, sz, _dp, _dp],
             "nlml": ctx + [_dp, _dp, _dp, sz, _dp, _dp],
             "nlml_predict": ctx + [_dp, _dp, _dp, sz, _dp, sz] + fl + [_dp],
+            "nlml_cross": ctx + [_dp, _dp, _dp, sz, _dp, _dp],
+            "nlml_cross_predict": ctx + [_dp, _dp, _dp, sz, _dp, sz] + fl + [_dp],
         }
         for name, argtypes in sig.items():
             f = self._fn(name)
@@ -393,15 +395,19 @@ class Api:
         return _Objective(self, X, yy, Xe, ye)
 
     def nlml(self, x, X, y, want_grad=True):
+        """len(x) == 4: (w_d, w_g, a_x, a_p), the NOCROSS build; len(x) == 5: (w_d, w_g, a, c, b), the lower-triangular ARD weight
+        matrix of the default build of test/gpr.cpp"""
         x, X, y = _f64(x), _points(X), _f64(y)
+        assert len(x) in (4, 5)
         val = C.c_double()
-        grad = np.empty(4) if want_grad else None
-        self._check(self._fn("nlml")(*self._c(), _ptr(x), _ptr(X), _ptr(y), len(X), C.cast(C.byref(val), _dp), _ptr(grad)))
+        grad = np.empty(len(x)) if want_grad else None
+        self._check(self._fn("nlml" if len(x) == 4 else "nlml_cross")(*self._c(), _ptr(x), _ptr(X), _ptr(y), len(X), C.cast(C.byref(val), _dp), _ptr(grad)))
         return val.value, grad
 
     def nlml_predict(self, x, X, y, Xs):
         x, X, y, Xs = _f64(x), _points(X), _f64(y), _points(Xs)
+        assert len(x) in (4, 5)
         out = np.empty(len(Xs))
-        self._check(self._fn("nlml_predict")(*self._c(), _ptr(x), _ptr(X), _ptr(y), len(X), _ptr(Xs), len(Xs), *self._fl(),
-                                             _ptr(out)))
+        self._check(self._fn("nlml_predict" if len(x) == 4 else "nlml_cross_predict")(*self._c(), _ptr(x), _ptr(X), _ptr(y), len(X), _ptr(Xs), len(Xs),
+                                                                                       *self._fl(), _ptr(out)))
         return out

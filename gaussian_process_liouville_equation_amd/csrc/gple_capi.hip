@@ -1547,7 +1547,7 @@ extern "C"
 
 	// ---- negative_log_marginal_likelihood / predict_phase (test/gpr.cpp:499-532, 654-706) -------------------------------
 	// shared: Gram, Cholesky, inverse factor, b = K^-1 y (labels are NOT rescaled on this path)
-	static int nlml_solve(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, Scratch& Xt, Scratch& yd, Scratch& T,
+	static int nlml_solve(gple_ctx* ctx, const double x[5], const double* X, const double* y, size_t N, Scratch& Xt, Scratch& yd, Scratch& T,
 		Scratch& bvec, int* n_out)
 	{
 		hipStream_t st = ctx->stream;
@@ -1578,36 +1578,50 @@ extern "C"
 		return GPLE_OK;
 	}
 
-	int gple_nlml(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, double* value, double* grad)
+	// n = 4: (w_d, w_g, a_x, a_p), the NOCROSS build; n = 5: (w_d, w_g, a, c, b), the default build's lower-triangular weight matrix
+	static void nlml_params(const double* x, size_t n, double x5[5])
+	{
+		x5[0] = x[0], x5[1] = x[1], x5[2] = x[2];
+		x5[3] = n == 5 ? x[3] : 0.0;
+		x5[4] = n == 5 ? x[4] : x[3];
+	}
+	static int nlml_impl(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N, double* value, double* grad)
 	{
 		if (!ctx || !x || !X || !y || !value || N == 0) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
+		double x5[5];
+		nlml_params(x, n, x5);
 		Scratch Xt(ctx), yd(ctx), T(ctx), b(ctx), out(ctx), W(ctx), part(ctx);
-		int n = 0;
-		GPLE_TRY(nlml_solve(ctx, x, X, y, N, Xt, yd, T, b, &n));
+		int np = 0;
+		GPLE_TRY(nlml_solve(ctx, x5, X, y, N, Xt, yd, T, b, &np));
 		GPLE_HIP(ctx, out.get(8));
-		GPLE_HIP(ctx, launch_nlml_value(st, T.p, n, yd.p, b.p, static_cast<int>(N), out.p));
+		GPLE_HIP(ctx, launch_nlml_value(st, T.p, np, yd.p, b.p, static_cast<int>(N), out.p));
 		if (grad)
 		{
 			const size_t g = (N + 63) / 64;
-			GPLE_HIP(ctx, W.get(static_cast<size_t>(n) * n));
-			GPLE_HIP(ctx, part.get(4 * g * g));
-			GPLE_HIP(ctx, lauum_full(st, T.p, n, W.p, n, n));
-			GPLE_HIP(ctx, launch_nlml_grad(st, Xt.p, static_cast<int>(N), W.p, n, b.p, x, part.p, out.p + 1));
+			GPLE_HIP(ctx, W.get(static_cast<size_t>(np) * np));
+			GPLE_HIP(ctx, part.get(5 * g * g));
+			GPLE_HIP(ctx, lauum_full(st, T.p, np, W.p, np, np));
+			GPLE_HIP(ctx, launch_nlml_grad(st, Xt.p, static_cast<int>(N), W.p, np, b.p, x5, part.p, out.p + 1));
 		}
-		GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_NLML, out.p, 5 * 8, hipMemcpyDeviceToHost, st));
+		GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_NLML, out.p, 6 * 8, hipMemcpyDeviceToHost, st));
 		GPLE_HIP(ctx, hipStreamSynchronize(st));
 		*value = ctx->host_scalars[HS_NLML];
 		if (grad)
-			for (int i = 0; i < 4; ++i) grad[i] = ctx->host_scalars[HS_NLML + 1 + i];
+		{
+			const double* g5 = ctx->host_scalars + HS_NLML + 1; // (w_d, w_g, a, c, b)
+			if (n == 5)
+				for (int i = 0; i < 5; ++i) grad[i] = g5[i];
+			else
+				grad[0] = g5[0], grad[1] = g5[1], grad[2] = g5[2], grad[3] = g5[4];
+		}
 		return GPLE_OK;
 	}
-
-	int gple_nlml_predict(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, const double* Xs, size_t M, unsigned flags,
-		double* mean)
+	static int nlml_predict_impl(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N, const double* Xs, size_t M,
+		unsigned flags, double* mean)
 	{
 		if (!ctx || !x || !X || !y || N == 0 || (M && (!Xs || !mean))) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
@@ -1616,9 +1630,11 @@ extern "C"
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
 		const bool dev = flags & GPLE_IO_DEVICE; // applies to Xs / mean only; the training set is small and host-side
+		double x5[5];
+		nlml_params(x, n, x5);
 		Scratch Xt(ctx), yd(ctx), T(ctx), b(ctx), xs(ctx), o(ctx);
-		int n = 0;
-		GPLE_TRY(nlml_solve(ctx, x, X, y, N, Xt, yd, T, b, &n));
+		int np = 0;
+		GPLE_TRY(nlml_solve(ctx, x5, X, y, N, Xt, yd, T, b, &np));
 		const double* xs_dev = Xs;
 		double* o_dev = mean;
 		if (!dev)
@@ -1628,9 +1644,28 @@ extern "C"
 			GPLE_HIP(ctx, copy_in(st, xs.p, Xs, 2 * M, false));
 			xs_dev = xs.p, o_dev = o.p;
 		}
-		GPLE_HIP(ctx, launch_nlml_predict(st, xs_dev, static_cast<int>(M), Xt.p, static_cast<int>(N), b.p, x, o_dev));
+		GPLE_HIP(ctx, launch_nlml_predict(st, xs_dev, static_cast<int>(M), Xt.p, static_cast<int>(N), b.p, x5, o_dev));
 		if (!dev) GPLE_HIP(ctx, copy_out(st, mean, o.p, M, false));
 		GPLE_HIP(ctx, hipStreamSynchronize(st));
 		return GPLE_OK;
+	}
+
+	int gple_nlml(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, double* value, double* grad)
+	{
+		return nlml_impl(ctx, x, 4, X, y, N, value, grad);
+	}
+	int gple_nlml_predict(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, const double* Xs, size_t M, unsigned flags,
+		double* mean)
+	{
+		return nlml_predict_impl(ctx, x, 4, X, y, N, Xs, M, flags, mean);
+	}
+	int gple_nlml_cross(gple_ctx* ctx, const double x[5], const double* X, const double* y, size_t N, double* value, double* grad)
+	{
+		return nlml_impl(ctx, x, 5, X, y, N, value, grad);
+	}
+	int gple_nlml_cross_predict(gple_ctx* ctx, const double x[5], const double* X, const double* y, size_t N, const double* Xs, size_t M,
+		unsigned flags, double* mean)
+	{
+		return nlml_predict_impl(ctx, x, 5, X, y, N, Xs, M, flags, mean);
 	}
 }

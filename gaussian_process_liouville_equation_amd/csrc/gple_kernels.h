@@ -98,12 +98,12 @@ namespace gple
 	hipError_t launch_sum(hipStream_t s, const double* part, int n, double* out);
 	hipError_t launch_cutoff(hipStream_t s, const double* pred, int is_complex, const double* var, int M, double* factor);
 
-	// ---- NLML path of test/gpr.cpp (gple_nlml.hip); x = (w_d, w_g, a_x, a_p) -------------------------------------------
-	hipError_t launch_nlml_gram(hipStream_t s, const double* Xt, int N, int n, const double x[4], double* K);
+	// ---- NLML path of test/gpr.cpp (gple_nlml.hip); x = (w_d, w_g, a, c, b): ARD weight matrix [[a, 0], [c, b]] --------------
+	hipError_t launch_nlml_gram(hipStream_t s, const double* Xt, int N, int n, const double x[5], double* K);
 	hipError_t launch_nlml_value(hipStream_t s, const double* T, long ldt, const double* y, const double* b, int N, double* out);
-	hipError_t launch_nlml_grad(hipStream_t s, const double* Xt, int N, const double* W, long ldw, const double* b, const double x[4], double* part,
-		double* out4);
-	hipError_t launch_nlml_predict(hipStream_t s, const double* Xs, int M, const double* Xt, int N, const double* b, const double x[4], double* mean);
+	hipError_t launch_nlml_grad(hipStream_t s, const double* Xt, int N, const double* W, long ldw, const double* b, const double x[5], double* part,
+		double* out5);
+	hipError_t launch_nlml_predict(hipStream_t s, const double* Xs, int M, const double* Xt, int N, const double* b, const double x[5], double* mean);
 
 	// ---- predict ------------------------------------------------------------------------------------------------
 	struct PredictArgs

@@ -1,9 +1,13 @@
 // gple_nlml.hip — negative log marginal likelihood + mean-only prediction of the older GPR prototype
 // (reference: test/gpr.cpp:368-396 Gram, :408-468 derivative matrices, :499-532 NLML, :654-706 predict_phase).
-// Kernel = w_d^2 DiagKernel + w_g^2 GaussianARDKernel with diagonal ARD weights a (inverse lengths):
-//   k(x, x') = w_g^2 exp(-|a o (x - x')|^2 / 2) + w_d^2 [training set and i == j]        (test/gpr.cpp:356-367, 384-388)
-// Shogun is absent from the reference tree (un-vendored, README names 6.1.4): the ARD kernel is restated from that
-// formula; parity is pinned by the oracle + numpy identities only ("parity unpinned").
+// Kernel = w_d^2 DiagKernel + w_g^2 GaussianARDKernel with the lower-triangular ARD weight matrix W = [[a, 0], [c, b]]
+// (test/gpr.cpp:313-321: "rowwise parameters", hyper-parameter order a = W(0,0), c = W(1,0), b = W(1,1); the NOCROSS build
+// of :323-326 is c = 0):
+//   k(x, x') = w_g^2 exp(-|W^T (x - x')|^2 / 2) + w_d^2 [training set and i == j]         (test/gpr.cpp:356-367, 384-388)
+// i.e. exp(-(x - x')^T M (x - x') / 2) with M = W W^T.  Shogun is absent from the reference tree (un-vendored, README names
+// 6.1.4): the ARD kernel and its "log_weights" gradient convention (diagonal entries in the log domain, hence the division
+// by the entry at :444, off-diagonal entries raw, :448) are restated from the formula comment and the call sites; parity is
+// pinned by the oracle + numpy identities only ("parity unpinned (Shogun)").
 #include "gple_kernels.h"
 
 namespace gple
@@ -29,14 +33,21 @@ namespace gple
 				for (int i = 0; i < NT / 64; ++i) tot += red[i];
 			return tot;
 		}
-		__device__ __forceinline__ double ard(double a0, double a1, double b0, double b1, double w0, double w1)
+		// u = W^T (x - y): u0 = a e0 + c e1, u1 = b e1
+		struct ArdW
 		{
-			const double d0 = __dmul_rn(w0, __dsub_rn(a0, b0)), d1 = __dmul_rn(w1, __dsub_rn(a1, b1));
+			double a, c, b;
+		};
+		__device__ __forceinline__ double ard(double a0, double a1, double b0, double b1, ArdW w, double* u0 = nullptr, double* u1 = nullptr)
+		{
+			const double e0 = __dsub_rn(a0, b0), e1 = __dsub_rn(a1, b1);
+			const double d0 = __dadd_rn(__dmul_rn(w.a, e0), __dmul_rn(w.c, e1)), d1 = __dmul_rn(w.b, e1);
+			if (u0) *u0 = d0, *u1 = d1;
 			return exp(__ddiv_rn(-__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), 2.0));
 		}
 
 		// padded training Gram (identity on the padding)
-		__global__ void __launch_bounds__(256) nlml_gram_kernel(const double* __restrict__ Xt, int N, int n, double wd, double wg, double a0, double a1,
+		__global__ void __launch_bounds__(256) nlml_gram_kernel(const double* __restrict__ Xt, int N, int n, double wd, double wg, ArdW w,
 			double* __restrict__ K)
 		{
 			const int i = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -47,7 +58,7 @@ namespace gple
 				double val = i == j ? 1.0 : 0.0;
 				if (i < N && j < N)
 				{
-					val = __dmul_rn(__dmul_rn(wg, wg), ard(Xt[2 * i], Xt[2 * i + 1], Xt[2 * j], Xt[2 * j + 1], a0, a1));
+					val = __dmul_rn(__dmul_rn(wg, wg), ard(Xt[2 * i], Xt[2 * i + 1], Xt[2 * j], Xt[2 * j + 1], w));
 					if (i == j) val = __dadd_rn(val, __dmul_rn(wd, wd)); // result += weight^2 * DiagKernel, test/gpr.cpp:392
 				}
 				K[i + static_cast<long>(j) * n] = val;
@@ -68,13 +79,14 @@ namespace gple
 			if (threadIdx.x == 0) out[0] = t0 / 2.0 + t1;
 		}
 		// part[ip][block] = sum over this tile of (W_ij - b_i b_j) dK_ip(j,i) with the reference's dK (test/gpr.cpp:408-468):
-		//   ip 0: w_d I (sic: weight * K_diag, not 2 w) ; ip 1: w_g G ; ip 2+d: w_g^2 / a_d * (-G a_d^2 (x_d - x'_d)^2)
+		//   ip 0: w_d I (sic: weight * K_diag, not 2 w) ; ip 1: w_g G ; then the weight-matrix entries in the order a, c, b:
+		//   w_g^2 dG/da = -w_g^2 G u0 e0 (:444: w^2 / a * dG/dlog a), w_g^2 dG/dc = -w_g^2 G u0 e1 (:448), w_g^2 dG/db = -w_g^2 G u1 e1
 		__global__ void __launch_bounds__(256) nlml_grad_kernel(const double* __restrict__ Xt, int N, const double* __restrict__ W, long ldw,
-			const double* __restrict__ b, double wd, double wg, double a0, double a1, double* __restrict__ part)
+			const double* __restrict__ b, double wd, double wg, ArdW w, double* __restrict__ part)
 		{
 			__shared__ double red[4];
 			const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-			double acc[4] = {0, 0, 0, 0};
+			double acc[5] = {0, 0, 0, 0, 0};
 			if (i < N)
 			{
 				const double x0 = Xt[2 * i], x1 = Xt[2 * i + 1], bi = b[i];
@@ -84,18 +96,20 @@ namespace gple
 					if (j < N)
 					{
 						const double y0 = Xt[2 * j], y1 = Xt[2 * j + 1];
-						const double g = ard(x0, x1, y0, y1, a0, a1);
+						double u0, u1;
+						const double g = ard(x0, x1, y0, y1, w, &u0, &u1);
 						const double m = W[i + static_cast<long>(j) * ldw] - bi * b[j];
 						acc[0] += m * (i == j ? wd : 0.0);
 						acc[1] += m * (wg * g);
 						const double e0 = x0 - y0, e1 = x1 - y1;
-						acc[2] += m * (wg * wg / a0 * (-g * a0 * a0 * e0 * e0));
-						acc[3] += m * (wg * wg / a1 * (-g * a1 * a1 * e1 * e1));
+						acc[2] += m * (wg * wg * (-g * u0 * e0));
+						acc[3] += m * (wg * wg * (-g * u0 * e1));
+						acc[4] += m * (wg * wg * (-g * u1 * e1));
 					}
 				}
 			}
 			const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
-			for (int ip = 0; ip < 4; ++ip)
+			for (int ip = 0; ip < 5; ++ip)
 			{
 				const double tot = block_sum<256>(acc[ip], red);
 				if (threadIdx.x == 0) part[ip * nblk + blk] = tot;
@@ -104,7 +118,7 @@ namespace gple
 		__global__ void __launch_bounds__(256) nlml_grad_sum_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out)
 		{
 			__shared__ double red[4];
-			for (int ip = 0; ip < 4; ++ip)
+			for (int ip = 0; ip < 5; ++ip)
 			{
 				double s = 0.0;
 				for (int i = threadIdx.x; i < nblk; i += 256) s += part[ip * nblk + i];
@@ -114,21 +128,21 @@ namespace gple
 		}
 		// mean-only prediction, the noise kernel is left out off the training set (test/gpr.cpp:384-388, 700)
 		__global__ void __launch_bounds__(256) nlml_predict_kernel(const double* __restrict__ Xs, int M, const double* __restrict__ Xt, int N,
-			const double* __restrict__ b, double wg, double a0, double a1, double* __restrict__ mean)
+			const double* __restrict__ b, double wg, ArdW w, double* __restrict__ mean)
 		{
 			const int i = blockIdx.x * 256 + threadIdx.x;
 			if (i >= M) return;
 			const double x0 = Xs[2 * i], x1 = Xs[2 * i + 1];
 			const double amp = wg * wg;
 			double acc = 0.0;
-			for (int k = 0; k < N; ++k) acc += __dmul_rn(amp, ard(x0, x1, Xt[2 * k], Xt[2 * k + 1], a0, a1)) * b[k];
+			for (int k = 0; k < N; ++k) acc += __dmul_rn(amp, ard(x0, x1, Xt[2 * k], Xt[2 * k + 1], w)) * b[k];
 			mean[i] = acc;
 		}
 	} // namespace
 
-	hipError_t launch_nlml_gram(hipStream_t s, const double* Xt, int N, int n, const double x[4], double* K)
+	hipError_t launch_nlml_gram(hipStream_t s, const double* Xt, int N, int n, const double x[5], double* K)
 	{
-		hipLaunchKernelGGL(nlml_gram_kernel, dim3(n / 64, n / 16), dim3(256), 0, s, Xt, N, n, x[0], x[1], x[2], x[3], K);
+		hipLaunchKernelGGL(nlml_gram_kernel, dim3(n / 64, n / 16), dim3(256), 0, s, Xt, N, n, x[0], x[1], (ArdW{x[2], x[3], x[4]}), K);
 		return hipGetLastError();
 	}
 	hipError_t launch_nlml_value(hipStream_t s, const double* T, long ldt, const double* y, const double* b, int N, double* out)
@@ -136,18 +150,18 @@ namespace gple
 		hipLaunchKernelGGL(nlml_value_kernel, dim3(1), dim3(1024), 0, s, T, ldt, y, b, N, out);
 		return hipGetLastError();
 	}
-	hipError_t launch_nlml_grad(hipStream_t s, const double* Xt, int N, const double* W, long ldw, const double* b, const double x[4], double* part,
-		double* out4)
+	hipError_t launch_nlml_grad(hipStream_t s, const double* Xt, int N, const double* W, long ldw, const double* b, const double x[5], double* part,
+		double* out5)
 	{
 		const int g = (N + 63) / 64;
-		hipLaunchKernelGGL(nlml_grad_kernel, dim3(g, g), dim3(256), 0, s, Xt, N, W, ldw, b, x[0], x[1], x[2], x[3], part);
-		hipLaunchKernelGGL(nlml_grad_sum_kernel, dim3(1), dim3(256), 0, s, part, g * g, out4);
+		hipLaunchKernelGGL(nlml_grad_kernel, dim3(g, g), dim3(256), 0, s, Xt, N, W, ldw, b, x[0], x[1], (ArdW{x[2], x[3], x[4]}), part);
+		hipLaunchKernelGGL(nlml_grad_sum_kernel, dim3(1), dim3(256), 0, s, part, g * g, out5);
 		return hipGetLastError();
 	}
-	hipError_t launch_nlml_predict(hipStream_t s, const double* Xs, int M, const double* Xt, int N, const double* b, const double x[4], double* mean)
+	hipError_t launch_nlml_predict(hipStream_t s, const double* Xs, int M, const double* Xt, int N, const double* b, const double x[5], double* mean)
 	{
 		if (M == 0) return hipSuccess;
-		hipLaunchKernelGGL(nlml_predict_kernel, dim3((M + 255) / 256), dim3(256), 0, s, Xs, M, Xt, N, b, x[1], x[2], x[3], mean);
+		hipLaunchKernelGGL(nlml_predict_kernel, dim3((M + 255) / 256), dim3(256), 0, s, Xs, M, Xt, N, b, x[1], (ArdW{x[2], x[3], x[4]}), mean);
 		return hipGetLastError();
 	}
 } // namespace gple

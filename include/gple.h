@@ -238,6 +238,15 @@ int gple_nlml(gple_ctx* ctx, const double x[4], const double* X, const double* y
 int gple_nlml_predict(gple_ctx* ctx, const double x[4], const double* X, const double* y, size_t N, const double* Xs,
 	size_t M, unsigned flags, double* mean);
 
+/* The default (cross-term) build of test/gpr.cpp (:99-103, 313-321, 436-452): the ARD kernel carries the lower-triangular weight
+ * matrix W = [[a, 0], [c, b]], k = w_g^2 exp(-|W^T (x - x')|^2 / 2) = w_g^2 exp(-(x - x')^T W W^T (x - x') / 2);
+ * x = (w_d, w_g, a, c, b) in the reference's hyper-parameter order ("rowwise parameters", :313-321).  grad (nullable, 5): the same
+ * trace formula with dK/da, dK/dc, dK/db scaled as at :436-452.  Shogun's matrix-weight kernel is restated from the formula
+ * comment (:356-367): parity unpinned (Shogun). */
+int gple_nlml_cross(gple_ctx* ctx, const double x[5], const double* X, const double* y, size_t N, double* value, double* grad);
+int gple_nlml_cross_predict(gple_ctx* ctx, const double x[5], const double* X, const double* y, size_t N, const double* Xs,
+	size_t M, unsigned flags, double* mean);
+
 #ifdef __cplusplus
 }
 #endif

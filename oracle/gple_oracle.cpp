@@ -1345,6 +1345,14 @@ extern "C"
 	// negative_log_marginal_likelihood (test/gpr.cpp:499-532) with kernels {Diag, GaussianARD(diagonal weights)}
 	// Shogun 6.1.4 GaussianARDKernel with vector weights a: k = exp(-|a o (x - x')|^2 / 2)   (test/gpr.cpp:356-367;
 	// weights are inverse lengths, test/gpr.cpp:167-173).  Shogun is absent: restated from that formula, parity unpinned.
+	// The default build carries the lower-triangular weight matrix W = [[a, 0], [c, b]] (test/gpr.cpp:313-321, hyper-parameter
+	// order a, c, b): k = exp(-|W^T (x - x')|^2 / 2); x5 = (w_d, w_g, a, c, b), the NOCROSS build is c = 0.
+	static void nlml_params(const double* x, size_t n, double x5[5])
+	{
+		x5[0] = x[0], x5[1] = x[1], x5[2] = x[2];
+		x5[3] = n == 5 ? x[3] : 0.0;
+		x5[4] = n == 5 ? x[4] : x[3];
+	}
 	static Mat nlml_gram(const double* x, const double* L, size_t R, const double* Rt, size_t C, bool training)
 	{
 		Mat K(R, C);
@@ -1352,7 +1360,8 @@ extern "C"
 		for (size_t j = 0; j < C; j++)
 			for (size_t i = 0; i < R; i++)
 			{
-				const double d0 = x[2] * (L[2 * i] - Rt[2 * j]), d1 = x[3] * (L[2 * i + 1] - Rt[2 * j + 1]);
+				const double e0 = L[2 * i] - Rt[2 * j], e1 = L[2 * i + 1] - Rt[2 * j + 1];
+				const double d0 = x[2] * e0 + x[3] * e1, d1 = x[4] * e1;
 				double k = x[1] * x[1] * std::exp(-(d0 * d0 + d1 * d1) / 2.0);
 				if (training && i == j) k += x[0] * x[0]; // DiagKernel only on the training set (test/gpr.cpp:384-388)
 				K(i, j) = k;
@@ -1405,9 +1414,11 @@ extern "C"
 		}
 	};
 
-	int oracle_nlml(const double x[4], const double* X, const double* y, size_t N, double* value, double* grad)
+	static int nlml_impl(const double* xin, size_t n, const double* X, const double* y, size_t N, double* value, double* grad)
 	{
-		if (!x || !X || !y || !value) return GPLE_ERR_BAD_ARG;
+		if (!xin || !X || !y || !value) return GPLE_ERR_BAD_ARG;
+		double x[5];
+		nlml_params(xin, n, x);
 		const Mat K = nlml_gram(x, X, N, X, N, true);
 		const LLT llt(K);
 		Mat KInv = identity<double>(N);
@@ -1422,40 +1433,41 @@ extern "C"
 		*value = r; // test/gpr.cpp:515
 		if (grad)
 		{
-			// dK as the reference builds it (test/gpr.cpp:408-468): weight * K_k for the two weights (sic: not 2 w K_k),
-			// weight^2 / a_d * dK_ard/dlog(a_d) for the ARD weights, with dk/dlog(a_d) = -k a_d^2 (x_d - x'_d)^2
-			for (int ip = 0; ip < 4; ip++)
+			// dK as the reference builds it (test/gpr.cpp:408-468): weight * K_k for the two weights (sic: not 2 w K_k); for the
+			// entries of W: weight^2 / W_jj * dG/dlog(W_jj) on the diagonal (:444), weight^2 * dG/dW_jk off it (:448), with
+			// u = W^T e: dG/da = -G u0 e0, dG/dc = -G u0 e1, dG/db = -G u1 e1
+			double g5[5];
+			for (int ip = 0; ip < 5; ip++)
 			{
 				double tr = 0.0;
 #pragma omp parallel for reduction(+ : tr) schedule(static)
 				for (size_t j = 0; j < N; j++)
 					for (size_t i = 0; i < N; i++)
 					{
-						const double d0 = x[2] * (X[2 * i] - X[2 * j]), d1 = x[3] * (X[2 * i + 1] - X[2 * j + 1]);
-						const double g = std::exp(-(d0 * d0 + d1 * d1) / 2.0);
+						const double e0 = X[2 * i] - X[2 * j], e1 = X[2 * i + 1] - X[2 * j + 1];
+						const double u0 = x[2] * e0 + x[3] * e1, u1 = x[4] * e1;
+						const double g = std::exp(-(u0 * u0 + u1 * u1) / 2.0);
 						double dk;
-						if (ip == 0)
-							dk = i == j ? x[0] : 0.0;
-						else if (ip == 1)
-							dk = x[1] * g;
-						else
-						{
-							const double diff = X[2 * i + (ip - 2)] - X[2 * j + (ip - 2)];
-							dk = x[1] * x[1] / x[ip] * (-g * x[ip] * x[ip] * diff * diff);
-						}
+						if (ip == 0) dk = i == j ? x[0] : 0.0;
+						else if (ip == 1) dk = x[1] * g;
+						else if (ip == 2) dk = x[1] * x[1] / x[2] * (-g * x[2] * u0 * e0);
+						else if (ip == 3) dk = x[1] * x[1] * (-g * u0 * e1);
+						else dk = x[1] * x[1] / x[4] * (-g * x[4] * u1 * e1);
 						// ((KInv - b b^T) * dK).trace() = sum_ij (KInv - b b^T)(i,j) dK(j,i)
 						tr += (KInv(i, j) - b.a[i] * b.a[j]) * dk;
 					}
-				grad[ip] = tr / 2.0; // test/gpr.cpp:525
+				g5[ip] = tr / 2.0; // test/gpr.cpp:525
 			}
+			if (n == 5) std::copy(g5, g5 + 5, grad);
+			else grad[0] = g5[0], grad[1] = g5[1], grad[2] = g5[2], grad[3] = g5[4];
 		}
 		return GPLE_OK;
 	}
-
-	int oracle_nlml_predict(const double x[4], const double* X, const double* y, size_t N, const double* Xs, size_t M,
-		double* mean)
+	static int nlml_predict_impl(const double* xin, size_t n, const double* X, const double* y, size_t N, const double* Xs, size_t M, double* mean)
 	{
-		if (!x || !X || !y || (!Xs && M) || !mean) return GPLE_ERR_BAD_ARG;
+		if (!xin || !X || !y || (!Xs && M) || !mean) return GPLE_ERR_BAD_ARG;
+		double x[5];
+		nlml_params(xin, n, x);
 		const Mat K = nlml_gram(x, X, N, X, N, true);
 		const LLT llt(K);
 		Mat b(N, 1);
@@ -1465,5 +1477,15 @@ extern "C"
 		const Vec mu = matvec(Ks, b.a); // test/gpr.cpp:700
 		std::copy(mu.begin(), mu.end(), mean);
 		return GPLE_OK;
+	}
+	int oracle_nlml(const double x[4], const double* X, const double* y, size_t N, double* value, double* grad) { return nlml_impl(x, 4, X, y, N, value, grad); }
+	int oracle_nlml_predict(const double x[4], const double* X, const double* y, size_t N, const double* Xs, size_t M, double* mean)
+	{
+		return nlml_predict_impl(x, 4, X, y, N, Xs, M, mean);
+	}
+	int oracle_nlml_cross(const double x[5], const double* X, const double* y, size_t N, double* value, double* grad) { return nlml_impl(x, 5, X, y, N, value, grad); }
+	int oracle_nlml_cross_predict(const double x[5], const double* X, const double* y, size_t N, const double* Xs, size_t M, double* mean)
+	{
+		return nlml_predict_impl(x, 5, X, y, N, Xs, M, mean);
 	}
 }

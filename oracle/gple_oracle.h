@@ -53,6 +53,10 @@ int oracle_nlml(const double x[4], const double* X, const double* y, size_t N, d
 int oracle_nlml_predict(const double x[4], const double* X, const double* y, size_t N, const double* Xs, size_t M,
 	double* mean);
 
+int oracle_nlml_cross(const double x[5], const double* X, const double* y, size_t N, double* value, double* grad);
+int oracle_nlml_cross_predict(const double x[5], const double* X, const double* y, size_t N, const double* Xs, size_t M,
+	double* mean);
+
 /* number of OpenMP threads the oracle will use (for the cpu_baseline "cores" field) */
 int oracle_num_threads(void);
 /* the OpenMP default (all online CPUs) oversubscribes a cgroup-limited box badly: oracle/binding.py sets this to the

@@ -33,7 +33,7 @@ def test_oracle_exports_the_mirror_interface():
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libgple_oracle.so"))
     for name in ["real_gram", "cutoff_factor", "real_fit_create", "real_fit_release", "real_fit_get", "real_predict",
                  "complex_fit_create", "complex_fit_release", "complex_fit_get", "complex_predict", "loose_function", "nlml",
-                 "nlml_predict"]:
+                 "nlml_predict", "nlml_cross", "nlml_cross_predict", "complex_gram"]:
         assert hasattr(lib, "oracle_" + name), name
 
 

@@ -226,6 +226,25 @@ def test_nlml_value_gradient_and_prediction(gpu, oracle):
     assert np.abs(mg - mo).max() <= 1e-9 * np.abs(mo).max()
 
 
+def test_nlml_cross_term_ard_against_oracle(gpu, oracle):
+    """gple_nlml_cross / gple_nlml_cross_predict (default build of test/gpr.cpp: lower-triangular ARD weight matrix, :313-321,
+    436-452) against the oracle, and c = 0 against the diagonal-ARD entry points"""
+    X, y, Xs = parity.synthetic_real(150, 300, 61)
+    x = np.array([0.1, 1.2, 1.0 / 0.8, 0.35, 1.0 / 0.7])
+    vg, gg = gpu.nlml(x, X, y)
+    vo, go = oracle.nlml(x, X, y)
+    assert abs(vg - vo) <= 1e-9 * abs(vo)
+    assert gg.shape == (5,) and np.abs(gg - go).max() <= 1e-7 * np.abs(go).max()
+    assert gpu.nlml(x, X, y, want_grad=False)[0] == vg
+    mg, mo = gpu.nlml_predict(x, X, y, Xs), oracle.nlml_predict(x, X, y, Xs)
+    assert np.abs(mg - mo).max() <= 1e-9 * np.abs(mo).max()
+    x4, x5 = np.array([0.1, 1.2, 1.25, 1.0 / 0.7]), np.array([0.1, 1.2, 1.25, 0.0, 1.0 / 0.7])
+    v4, g4 = gpu.nlml(x4, X, y)
+    v5, g5 = gpu.nlml(x5, X, y)
+    assert v4 == v5 and np.array_equal(g4, g5[[0, 1, 2, 4]])
+    assert np.array_equal(gpu.nlml_predict(x4, X, y, Xs), gpu.nlml_predict(x5, X, y, Xs))
+
+
 @pytest.mark.parametrize("N", [2100, 4096])
 def test_large_fit_identities(gpu, N):
     """Sizes that take the 128-tile MFMA GEMMs and an uneven merge tree (Np = 2304 -> 36 diagonal blocks; 4096 -> the

@@ -102,3 +102,42 @@ def test_nlml_gradient_structure(oracle):
     Ks = x[1] ** 2 * np.exp(-0.5 * (d0 ** 2 + d1 ** 2))
     K = x[1] ** 2 * np.exp(-0.5 * ((x[2] * (X[:, None, 0] - X[None, :, 0])) ** 2 + (x[3] * (X[:, None, 1] - X[None, :, 1])) ** 2)) + x[0] ** 2 * np.eye(len(X))
     assert np.abs(mean - Ks @ np.linalg.solve(K, y)).max() <= 1e-9 * np.abs(mean).max()
+
+
+def test_nlml_cross_term_ard(oracle):
+    """The default build of test/gpr.cpp (:99-103, 313-321, 436-452): lower-triangular ARD weight matrix W = [[a, 0], [c, b]],
+    k = exp(-(x - x')^T W W^T (x - x') / 2).  Value against numpy; the three weight-matrix gradients are true derivatives (the
+    log-domain diagonal convention divided out at :444), the two kernel-weight gradients half of it as in the NOCROSS build;
+    c = 0 reproduces the diagonal-ARD entry point exactly.  Parity unpinned (Shogun)."""
+    X, y, Xs = parity.synthetic_real(30, 10, 8)
+    x = np.array([0.1, 1.2, 1.0 / 0.8, 0.35, 1.0 / 0.7])  # (w_d, w_g, a, c, b)
+    val, grad = oracle.nlml(x, X, y)
+
+    def gram(xx, A, B):
+        e0, e1 = A[:, None, 0] - B[None, :, 0], A[:, None, 1] - B[None, :, 1]
+        W = np.array([[xx[2], 0.0], [xx[3], xx[4]]])
+        Mm = W @ W.T
+        q = Mm[0, 0] * e0 ** 2 + 2 * Mm[0, 1] * e0 * e1 + Mm[1, 1] * e1 ** 2
+        return xx[1] ** 2 * np.exp(-0.5 * q)
+
+    def f(xx):
+        K = gram(xx, X, X) + xx[0] ** 2 * np.eye(len(X))
+        return 0.5 * y @ np.linalg.solve(K, y) + np.log(np.diag(np.linalg.cholesky(K))).sum()
+
+    assert abs(val - f(x)) <= 1e-10 * abs(val)
+    for ip in range(5):
+        h = 1e-6 * x[ip]
+        xp, xm = x.copy(), x.copy()
+        xp[ip] += h
+        xm[ip] -= h
+        fd = (f(xp) - f(xm)) / (2 * h)
+        expect = fd / 2 if ip < 2 else fd
+        assert abs(grad[ip] - expect) <= 1e-5 * max(1.0, abs(expect)), (ip, grad[ip], expect)
+    mean = oracle.nlml_predict(x, X, y, Xs)
+    K = gram(x, X, X) + x[0] ** 2 * np.eye(len(X))
+    assert np.abs(mean - gram(x, Xs, X) @ np.linalg.solve(K, y)).max() <= 1e-9 * np.abs(mean).max()
+    x4 = np.array([0.1, 1.2, 1.0 / 0.8, 1.0 / 0.7])
+    x5 = np.array([0.1, 1.2, 1.0 / 0.8, 0.0, 1.0 / 0.7])
+    v4, g4 = oracle.nlml(x4, X, y)
+    v5, g5 = oracle.nlml(x5, X, y)
+    assert v4 == v5 and np.allclose(g4, g5[[0, 1, 2, 4]], rtol=1e-12, atol=0)  # OpenMP reduction order only
