@@ -8,6 +8,8 @@
 //   explicit inverse W    : n_total x n_total, built only for get_inverse()/derivatives (W = T^T T)
 // A fit handle owns Xt, ys, T, v, w (+ lazily W and the derivative vectors); the Cholesky work matrix, the merge-tree
 // workspace and all predict scratch belong to the context's buffer pool and are reused across calls.
+#include <dlfcn.h>
+
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -636,7 +638,8 @@ extern "C"
 		case GPLE_ERR_BAD_ARG: return "bad argument";
 		case GPLE_ERR_HIP: return "HIP runtime error";
 		case GPLE_ERR_ALLOC: return "device allocation failed";
-		case GPLE_ERR_STATE: return "requested output was not computed by this fit (flags)";
+		case GPLE_ERR_STATE: return "requested output was not computed by this fit (flags), or the context was destroyed";
+		case GPLE_ERR_COLLECTIVE: return "RCCL collective failed or librccl could not be resolved";
 		default: return "unknown status";
 		}
 	}
@@ -1381,6 +1384,148 @@ extern "C"
 		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
 		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
+	}
+
+	// ---- grid-sharded predict: slice -> predict -> ncclAllGather -> unpack ------------------------------------------------------
+	int gple_shard_bounds(size_t M, int rank, int world, size_t* lo, size_t* hi, size_t* per)
+	{
+		if (world <= 0 || rank < 0 || rank >= world) return GPLE_ERR_BAD_ARG;
+		const size_t p = M ? (M + static_cast<size_t>(world) - 1) / static_cast<size_t>(world) : 0; // parallel.shard_bounds
+		const size_t l = std::min(M, static_cast<size_t>(rank) * p), h = std::min(M, l + p);
+		if (lo) *lo = l;
+		if (hi) *hi = h;
+		if (per) *per = p;
+		return GPLE_OK;
+	}
+	namespace
+	{
+		// RCCL's C entry point, resolved lazily: from the process image when the caller links librccl (their ncclComm_t then
+		// belongs to that very library), else from librccl.so.1.  No RCCL header or link dependency in this library.
+		using allgather_fn = int (*)(const void*, void*, size_t, int, void*, hipStream_t);
+		std::atomic<allgather_fn> allgather_override{nullptr};
+		allgather_fn resolve_allgather()
+		{
+			if (allgather_fn o = allgather_override.load()) return o;
+			static allgather_fn fn = [] {
+				void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+				if (!sym)
+					for (const char* name : {"librccl.so.1", "librccl.so"})
+						if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))
+							if ((sym = dlsym(h, "ncclAllGather"))) break;
+				return reinterpret_cast<allgather_fn>(sym);
+			}();
+			return fn;
+		}
+		// gathered[r][...] (world blocks of (2 ow + 1) * per doubles: mean | var | cut of rank r's slice) -> full-length outputs
+		__global__ void __launch_bounds__(256) unshard_kernel(const double* __restrict__ g, size_t per, int ow, size_t M, double* __restrict__ mean,
+			double* __restrict__ var, double* __restrict__ cut)
+		{
+			const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+			if (i >= M) return;
+			const size_t r = i / per, q = i % per;
+			const double* __restrict__ blk = g + r * (2 * ow + 1) * per;
+			for (int k = 0; k < ow; ++k)
+			{
+				if (mean) mean[ow * i + k] = blk[ow * q + k];
+				if (cut) cut[ow * i + k] = blk[(ow + 1) * per + ow * q + k];
+			}
+			if (var) var[i] = blk[ow * per + q];
+		}
+	} // namespace
+	int gple_set_allgather_function(void* fn)
+	{
+		allgather_override.store(reinterpret_cast<allgather_fn>(fn));
+		return GPLE_OK;
+	}
+	static int predict_sharded(gple_ctx* ctx, const FitCommon* f, const double* Xs, size_t M, unsigned flags, int rank, int world, void* comm,
+		double* prediction, double* variance, double* cutoff_prediction)
+	{
+		size_t lo, hi, per;
+		GPLE_TRY(gple_shard_bounds(M, rank, world, &lo, &hi, &per));
+		if (world > 1 && !comm) return GPLE_ERR_BAD_ARG;
+		if (M == 0) return GPLE_OK;
+		const bool dev = flags & GPLE_IO_DEVICE;
+		if (!comm) return predict_common(ctx, f, Xs, M, flags & GPLE_IO_DEVICE, nullptr, prediction, variance, cutoff_prediction, nullptr);
+		const allgather_fn allgather = resolve_allgather();
+		if (!allgather)
+		{
+			std::lock_guard<std::mutex> lk(ctx->mu);
+			ctx->last_error = std::string("ncclAllGather not found: ") + (dlerror() ? dlerror() : "librccl is not loadable");
+			return GPLE_ERR_COLLECTIVE;
+		}
+		const size_t ow = f->is_complex ? 2 : 1, blk = (2 * ow + 1) * per;
+		hipStream_t st = ctx->stream;
+		// the slice goes through device buffers whatever the caller's pointers are: the collective runs on device memory
+		Scratch local(ctx), gathered(ctx), xs(ctx), om(ctx), ov(ctx), oc(ctx);
+		const double* xs_dev = Xs + 2 * lo;
+		{
+			std::lock_guard<std::mutex> lk(ctx->call_mu);
+			GPLE_HIP(ctx, hipSetDevice(ctx->device));
+			GPLE_HIP(ctx, local.get(blk));
+			GPLE_HIP(ctx, gathered.get(blk * world));
+			GPLE_HIP(ctx, hipMemsetAsync(local.p, 0, blk * 8, st)); // the padded tail of the last rank's slice
+			if (!dev && hi > lo)
+			{
+				GPLE_HIP(ctx, xs.get(2 * (hi - lo)));
+				GPLE_HIP(ctx, copy_in(st, xs.p, Xs + 2 * lo, 2 * (hi - lo), false));
+				xs_dev = xs.p;
+			}
+		}
+		if (hi > lo)
+			GPLE_TRY(predict_common(ctx, f, xs_dev, hi - lo, GPLE_IO_DEVICE, nullptr, local.p, local.p + ow * per, local.p + (ow + 1) * per, nullptr));
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		const int rc = allgather(local.p, gathered.p, blk, /* ncclDouble */ 8, comm, st);
+		if (rc != 0)
+		{
+			std::lock_guard<std::mutex> l2(ctx->mu);
+			ctx->last_error = "ncclAllGather returned " + std::to_string(rc);
+			return GPLE_ERR_COLLECTIVE;
+		}
+		double *d_mean = prediction, *d_var = variance, *d_cut = cutoff_prediction;
+		if (!dev)
+		{
+			if (prediction)
+			{
+				GPLE_HIP(ctx, om.get(ow * M));
+				d_mean = om.p;
+			}
+			if (variance)
+			{
+				GPLE_HIP(ctx, ov.get(M));
+				d_var = ov.p;
+			}
+			if (cutoff_prediction)
+			{
+				GPLE_HIP(ctx, oc.get(ow * M));
+				d_cut = oc.p;
+			}
+		}
+		hipLaunchKernelGGL(unshard_kernel, dim3(static_cast<unsigned>((M + 255) / 256)), dim3(256), 0, st, gathered.p, per, static_cast<int>(ow), M, d_mean, d_var, d_cut);
+		GPLE_HIP(ctx, hipGetLastError());
+		if (!dev)
+		{
+			GPLE_HIP(ctx, copy_out(st, prediction, d_mean, ow * M, false));
+			GPLE_HIP(ctx, copy_out(st, variance, d_var, M, false));
+			GPLE_HIP(ctx, copy_out(st, cutoff_prediction, d_cut, ow * M, false));
+			GPLE_HIP(ctx, hipStreamSynchronize(st));
+			timer_collect(ctx);
+		}
+		return GPLE_OK;
+	}
+	int gple_real_predict_sharded(gple_ctx* ctx, const gple_real_fit* fit, const double* Xs, size_t M, unsigned flags, int rank, int world,
+		void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction)
+	{
+		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		return predict_sharded(ctx, fit, Xs, M, flags, rank, world, nccl_comm, prediction, variance, cutoff_prediction);
+	}
+	int gple_complex_predict_sharded(gple_ctx* ctx, const gple_complex_fit* fit, const double* Xs, size_t M, unsigned flags, int rank, int world,
+		void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction)
+	{
+		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		return predict_sharded(ctx, fit, Xs, M, flags, rank, world, nccl_comm, prediction, variance, cutoff_prediction);
 	}
 
 	// ---- batched point-predict (N1): gather -> one predict per element -> scatter ------------------------------------

@@ -33,6 +33,7 @@ extern "C" {
 #define GPLE_ERR_BAD_ARG 1
 #define GPLE_ERR_HIP 2
 #define GPLE_ERR_ALLOC 3
+#define GPLE_ERR_COLLECTIVE 5 /* RCCL could not be resolved or a collective failed (gple_ctx_last_error has the text) */
 #define GPLE_ERR_STATE 4 /* e.g. derivative output requested from a fit built without GPLE_CALC_DERIVATIVE; call on a destroyed context */
 
 /* The three bools of the Training*Kernel constructors (kernel.h:128-134, complex_kernel.h:167-173). */
@@ -210,6 +211,23 @@ int gple_objective_create(gple_ctx* ctx, const double* X, const double* y, size_
 /* loose_function(x, grad, params): n = 4 (real element) or 8 (complex element); grad may be NULL. */
 int gple_objective_eval(gple_objective* objective, const double* x, size_t n, double* value, double* grad);
 int gple_objective_release(gple_objective* objective);
+
+/* ---- grid-sharded predict for C++ callers (output.cpp:181-233 over several GPUs) ---------------------- */
+/* One process per GPU; every rank holds the same fit (replicated: DESIGN.md §7) and calls this with the WHOLE grid Xs (2M).
+ * The rank predicts its contiguous slice [lo, hi) of gple_shard_bounds and the slices are all-gathered with ncclAllGather on
+ * the context's stream (RCCL over xGMI), so that prediction / variance / cutoff_prediction (each nullable, full length M resp.
+ * 2M for the complex kernel) are complete on every rank when the call returns (host outputs) or when the stream reaches that
+ * point (GPLE_IO_DEVICE).  nccl_comm is the caller's ncclComm_t; the RCCL entry points are resolved at first use from the
+ * process (the caller links librccl) or from librccl.so.1.  world == 1 with nccl_comm == NULL is the plain predict. */
+int gple_shard_bounds(size_t M, int rank, int world, size_t* lo, size_t* hi, size_t* per);
+/* Callers with another transport (MPI, host staging) plug their own all-gather: same signature and semantics as
+ * ncclAllGather(sendbuff, recvbuff, sendcount, datatype = 8 (double), comm, hipStream_t), device buffers, 0 = success.
+ * NULL restores RCCL.  Process-wide; set it before the first sharded call of any thread. */
+int gple_set_allgather_function(void* fn);
+int gple_real_predict_sharded(gple_ctx* ctx, const gple_real_fit* fit, const double* Xs, size_t M, unsigned flags, int rank, int world,
+	void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction);
+int gple_complex_predict_sharded(gple_ctx* ctx, const gple_complex_fit* fit, const double* Xs, size_t M, unsigned flags, int rank,
+	int world, void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction);
 
 /* ---- batched point-predict ------------------------------------------------------------------ */
 /* The reference evaluates its DistributionFunction (stdafx.h:155) one phase-space point at a time: main.cpp:75-101 constructs a

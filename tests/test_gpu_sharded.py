@@ -1,0 +1,115 @@
+"""GPU: the grid-sharded predict of the C-ABI (gple_*_predict_sharded: slice -> predict -> ncclAllGather -> unpack), the native
+counterpart of parallel.GridShardedStep for C++ callers (output.cpp:181-233 over several GPUs).
+  * real RCCL with a one-rank communicator (a one-GPU box cannot hold two RCCL ranks on one device);
+  * world = 2 and 3 as host threads with separate contexts on the one GPU, through an in-process all-gather plugged in with
+    gple_set_allgather_function (tests/cpp/fake_allgather.cpp) — every rank must end up with the unsharded result, bit for bit."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from gaussian_process_liouville_equation_amd import _capi as c
+from gaussian_process_liouville_equation_amd import parallel
+from tests import parity
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+_dp = C.POINTER(C.c_double)
+
+
+def _sharded(api, fit, Xs, rank, world, comm, cplx):
+    M = len(Xs)
+    ow = 2 if cplx else 1
+    mean, var, cut = np.empty(ow * M), np.empty(M), np.empty(ow * M)
+    fn = api.lib.gple_complex_predict_sharded if cplx else api.lib.gple_real_predict_sharded
+    fn.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, C.c_uint, C.c_int, C.c_int, C.c_void_p, _dp, _dp, _dp]
+    Xs = np.ascontiguousarray(Xs)
+    st = fn(api.ctx, fit.handle, Xs.ctypes.data_as(_dp), M, 0, rank, world, comm, mean.ctypes.data_as(_dp), var.ctypes.data_as(_dp), cut.ctypes.data_as(_dp))
+    assert st == 0, (st, api.lib.gple_ctx_last_error(api.ctx))
+    return (mean.view(np.complex128), var, cut.view(np.complex128)) if cplx else (mean, var, cut)
+
+
+def test_shard_bounds_match_the_python_partition(gpu):
+    lo, hi, per = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    gpu.lib.gple_shard_bounds.argtypes = [C.c_size_t, C.c_int, C.c_int] + [C.POINTER(C.c_size_t)] * 3
+    for M in (0, 1, 7, 64, 65537):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert gpu.lib.gple_shard_bounds(M, r, world, C.byref(lo), C.byref(hi), C.byref(per)) == 0
+                assert (lo.value, hi.value, per.value) == parallel.shard_bounds(M, r, world)
+    assert gpu.lib.gple_shard_bounds(10, 2, 2, None, None, None) == 1
+
+
+def test_sharded_predict_with_real_rccl_single_rank(gpu):
+    path = "/opt/rocm/lib/librccl.so.1"
+    if not os.path.exists(path):
+        pytest.skip("no system RCCL on this box")
+    rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)  # the library resolves ncclAllGather from the process image first
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    gpu.lib.gple_set_allgather_function(None)
+    X, y, Xs = parity.synthetic_real(200, 777, 5)
+    fit = gpu.real_fit([1.0, 0.7086, 0.7056, 1e-2], X, y, 0)
+    ref = gpu.real_predict(fit, Xs)
+    mean, var, cut = _sharded(gpu, fit, Xs, 0, 1, comm, False)
+    assert np.array_equal(mean, ref["prediction"]) and np.array_equal(var, ref["variance"]) and np.array_equal(cut, ref["cutoff"])
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("world,cplx", [(2, False), (3, False), (2, True)])
+def test_sharded_predict_between_threads(gpu, world, cplx):
+    so = os.path.join(ROOT, "tests", "cpp", "libfake_allgather.so")
+    if not os.path.exists(so):
+        pytest.fail("tests/cpp/libfake_allgather.so missing: run __graft_entry__.build()")
+    import gaussian_process_liouville_equation_amd as pkg
+    fake = C.CDLL(so)
+    fake.fake_group_create.restype = C.c_void_p
+    fake.fake_comm_create.restype = C.c_void_p
+    fake.fake_comm_create.argtypes = [C.c_void_p, C.c_int]
+    fake.fake_comm_destroy.argtypes = [C.c_void_p]
+    fake.fake_group_destroy.argtypes = [C.c_void_p]
+    gpu.lib.gple_set_allgather_function.argtypes = [C.c_void_p]
+    gpu.lib.gple_set_allgather_function(C.cast(fake.fake_allgather, C.c_void_p))
+    try:
+        M = 1001  # not a multiple of world: the last slice is shorter than `per`
+        X, yr, Xs = parity.synthetic_real(150, M, 9)
+        y = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0)) if cplx else yr
+        theta = [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05] if cplx else [1.0, 0.7086, 0.7056, 1e-2]
+        # reference: the unsharded slices, one call per slice (the split of the mean's k-sum depends on the rows of a call)
+        fit0 = (gpu.complex_fit if cplx else gpu.real_fit)(theta, X, y, 0)
+        pred = gpu.complex_predict if cplx else gpu.real_predict
+        parts = [pred(fit0, Xs[lo:hi]) for lo, hi, _ in (parallel.shard_bounds(M, r, world) for r in range(world))]
+        ref = {k: np.concatenate([p[k] for p in parts]) for k in ("prediction", "variance", "cutoff")}
+        group = fake.fake_group_create(world)
+        out, errs = {}, []
+
+        def rank_main(r):
+            try:
+                api = pkg.open_api(0)  # one context (= stream) per rank, the fit replicated like on a real node
+                fit = (api.complex_fit if cplx else api.real_fit)(theta, X, y, 0)
+                comm = fake.fake_comm_create(group, r)
+                out[r] = _sharded(api, fit, Xs, r, world, comm, cplx)
+                fake.fake_comm_destroy(comm)
+                api.close()
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join(timeout=120) for t in th]
+        assert not errs, errs
+        fake.fake_group_destroy(group)
+        for r in range(world):
+            mean, var, cut = out[r]
+            assert np.array_equal(mean, ref["prediction"]) and np.array_equal(var, ref["variance"]) and np.array_equal(cut, ref["cutoff"])
+    finally:
+        gpu.lib.gple_set_allgather_function(None)
