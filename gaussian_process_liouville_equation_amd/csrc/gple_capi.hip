@@ -140,6 +140,13 @@ static void ctx_drop(gple_ctx* ctx)
 	if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
 	timer_collect(ctx);
 	for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
+	if (ctx->side_stream)
+	{
+		(void)hipStreamSynchronize(ctx->side_stream);
+		(void)hipStreamDestroy(ctx->side_stream);
+		if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+		if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
+	}
 	if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -297,7 +304,7 @@ namespace
 		const size_t ylen = N * static_cast<size_t>(y_stride);
 		GPLE_HIP(ctx, ytmp.get(ylen));
 		GPLE_HIP(ctx, Lbuf.get(static_cast<size_t>(nt) * nt));
-		GPLE_HIP(ctx, work.get(static_cast<size_t>(nt) * nt / 4 + 64));
+		GPLE_HIP(ctx, work.get(chol_inverse_work_doubles(nt)));
 		GPLE_HIP(ctx, part.get(static_cast<size_t>(nt / 256) * nt));
 		GPLE_HIP(ctx, u.get(nt));
 
@@ -316,8 +323,7 @@ namespace
 		GPLE_HIP(ctx, hipMemsetAsync(f->T, 0, static_cast<size_t>(nt) * nt * 8, st));
 		GPLE_HIP(ctx, launch_gram_train(st, f->Xt, f->N, Np, nt, f->ps, Lbuf.p, nt));
 		int* info_dev = reinterpret_cast<int*>(f->sdev + 31);
-		GPLE_HIP(ctx, potrf_lower(st, Lbuf.p, nt, nt, f->T, nt, info_dev));
-		GPLE_HIP(ctx, trtri_lower_from_diag(st, Lbuf.p, nt, f->T, nt, nt, work.p));
+		GPLE_HIP(ctx, chol_inverse_factor(ctx, st, Lbuf.p, nt, nt, f->T, nt, info_dev, work.p));
 		GPLE_HIP(ctx, launch_trmv_lower(st, f->T, nt, nt, f->ys, part.p, u.p));
 		GPLE_HIP(ctx, launch_colpass(st, f->T, nt, nt, u.p, f->v, f->w, Np, f->wx));
 		return GPLE_OK;
@@ -1704,7 +1710,7 @@ extern "C"
 		GPLE_HIP(ctx, T.get(static_cast<size_t>(n) * n));
 		GPLE_HIP(ctx, bvec.get(n));
 		GPLE_HIP(ctx, L.get(static_cast<size_t>(n) * n));
-		GPLE_HIP(ctx, work.get(static_cast<size_t>(n) * n / 4 + 64));
+		GPLE_HIP(ctx, work.get(chol_inverse_work_doubles(n)));
 		GPLE_HIP(ctx, part.get(static_cast<size_t>(n / 256) * n));
 		GPLE_HIP(ctx, u.get(n));
 		GPLE_HIP(ctx, w.get(n));
@@ -1716,8 +1722,7 @@ extern "C"
 		GPLE_HIP(ctx, copy_in(st, Xt.p, X, 2 * N, false));
 		GPLE_HIP(ctx, copy_in(st, yd.p, y, N, false));
 		GPLE_HIP(ctx, launch_nlml_gram(st, Xt.p, static_cast<int>(N), n, x, L.p));
-		GPLE_HIP(ctx, potrf_lower(st, L.p, n, n, T.p, n, reinterpret_cast<int*>(info.p)));
-		GPLE_HIP(ctx, trtri_lower_from_diag(st, L.p, n, T.p, n, n, work.p));
+		GPLE_HIP(ctx, chol_inverse_factor(ctx, st, L.p, n, n, T.p, n, reinterpret_cast<int*>(info.p), work.p));
 		GPLE_HIP(ctx, launch_trmv_lower(st, T.p, n, n, yd.p, part.p, u.p));
 		GPLE_HIP(ctx, launch_colpass(st, T.p, n, n, u.p, bvec.p, w.p, 0, nullptr));
 		return GPLE_OK;

@@ -7,6 +7,7 @@
 // tree of MFMA GEMMs, and only on request W = K^-1 = T^T T.  A non-positive pivot does not abort: sqrt() yields
 // NaN which propagates into every output, and *info records the first offending column (reference behaviour:
 // LDLT::info() is never checked, NaN/Inf are clamped later by opt.cpp:420-431).
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -181,6 +182,80 @@ namespace gple
 			}
 		}
 
+		// ---- column-split panel kernel -----------------------------------------------------------------------------------
+		// The sweep above keeps a whole 64-entry row per lane, so the wave that owns the diagonal block issues up to 63 fp64
+		// FMAs (8 cycles each) per column on top of the pivot chain: ~700 cycles per column, issue-bound.  Here the 64 columns
+		// of a row block are dealt out to four waves of 16 columns: per column every wave applies at most 16 FMAs, and only
+		// the wave that owns the pivot column runs the 1/sqrt chain.  Workgroup = 8 waves: waves 0-3 hold the diagonal block
+		// (re-factored per workgroup, as above), waves 4-7 hold 64 rows below it; lane = row, one barrier per column with the
+		// published column double-buffered in LDS.
+		constexpr int P16_THREADS = 512, P16_COLS = 16;
+		template <int K>
+		__device__ __forceinline__ void panel16_column(double (&a)[P16_COLS], double (*colD)[NB + 2], double (*colB)[NB], double* rinv, int lane, int role,
+			int cg, int& first_bad)
+		{
+			constexpr int G = K / P16_COLS, C = K % P16_COLS, BUF = K & 1;
+			if (cg == G) // uniform per wave: this wave owns column K of its row block
+			{
+				if (role == 0)
+				{
+					const double d = readlane_f64(a[C], K);
+					first_bad = (first_bad == 0 && !(d > 0.0)) ? K + 1 : first_bad;
+					const double r0 = rsqrt_newton(d); // NaN for d <= 0: propagates, like the sqrt of a negative pivot
+					double sd = d * r0;
+					sd = fma(fma(-sd, sd, d), 0.5 * r0, sd); // sqrt(d) with a correction step
+					colD[BUF][lane] = lane == K ? sd : (lane > K ? a[C] * r0 : 0.0);
+					if (lane == 0) rinv[BUF] = r0;
+				}
+				else
+					colB[BUF][lane] = a[C]; // raw entries of column K of the rows below; scaled by 1 / L_KK after the barrier
+			}
+			__syncthreads();
+			if (cg >= G) // waves whose columns are all left of K have nothing left to do
+			{
+				const double l = role == 0 ? colD[BUF][lane] : colB[BUF][lane] * rinv[BUF];
+				if (cg == G) a[C] = l;
+#pragma unroll
+				for (int jj = 0; jj < P16_COLS; ++jj)
+				{
+					// column index 16 cg + jj > K  <=>  cg > G, or cg == G and jj > C; the second case is resolved at compile time
+					if (jj > C) a[jj] = fma(-l, colD[BUF][cg * P16_COLS + jj], a[jj]);
+					else if (cg > G) a[jj] = fma(-l, colD[BUF][cg * P16_COLS + jj], a[jj]);
+				}
+			}
+		}
+		template <int... Ks>
+		__device__ __forceinline__ void panel16_columns(double (&a)[P16_COLS], double (*colD)[NB + 2], double (*colB)[NB], double* rinv, int lane, int role,
+			int cg, int& first_bad, std::integer_sequence<int, Ks...>)
+		{
+			(panel16_column<Ks>(a, colD, colB, rinv, lane, role, cg, first_bad), ...);
+		}
+		__global__ void __launch_bounds__(P16_THREADS) potrf_panel16_kernel(double* __restrict__ A, long lda, int m, int* __restrict__ info, int j0,
+			double* __restrict__ D, long ldd)
+		{
+			__shared__ __attribute__((aligned(16))) double colD[2][NB + 2];
+			__shared__ __attribute__((aligned(16))) double colB[2][NB];
+			__shared__ double rinv[2];
+			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int role = w >> 2, cg = w & 3;
+			const int row = role == 0 ? lane : NB + blockIdx.x * NB + lane;
+			const bool valid = row < m;
+			double a[P16_COLS];
+			const double* __restrict__ src = A + (valid ? row : 0) + static_cast<long>(cg * P16_COLS) * lda;
+#pragma unroll
+			for (int j = 0; j < P16_COLS; ++j) a[j] = src[static_cast<long>(j) * lda];
+			int first_bad = 0;
+			panel16_columns(a, colD, colB, rinv, lane, role, cg, first_bad, std::make_integer_sequence<int, NB>{});
+			if (first_bad != 0 && lane == 0 && role == 0 && blockIdx.x == 0) atomicCAS(info, 0, j0 + first_bad); // info starts at 0
+			if (valid && (role == 1 || blockIdx.x == 0))
+			{
+				double* __restrict__ dst = (role == 0 ? D + row + static_cast<long>(cg * P16_COLS) * ldd : A + row + static_cast<long>(cg * P16_COLS) * lda);
+				const long ld = role == 0 ? ldd : lda;
+#pragma unroll
+				for (int j = 0; j < P16_COLS; ++j) dst[static_cast<long>(j) * ld] = a[j];
+			}
+		}
+
 		// Tinv_b = L_b^-1 for every 64 x 64 diagonal block b of the factor (one wave per block, all blocks in one launch):
 		// lane j owns column j of the inverse and runs its own forward substitution; row r of L is an LDS broadcast.
 		// Called in place (L == T: the panel kernel leaves L_b in T's diagonal blocks): a block is read completely into LDS
@@ -237,26 +312,75 @@ namespace gple
 
 	} // namespace
 
-	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info)
+	// Two-level blocking.  A 64-wide panel step that updates the WHOLE trailing matrix reads and writes it once per panel:
+	// 8 n^3 / (3 * 64) bytes in total, 2.9 GB at n = 4096 — the K = 64 updates run at HBM speed, not MFMA speed (1.07 ms of
+	// the 3.3 ms fit).  With an outer block of OB columns the panel steps only update the rest of their own block column
+	// (a strip of <= OB - 64 columns), and the matrix right of the block gets ONE update with K = OB per outer block: a
+	// quarter of the traffic at OB = 256, at four times the arithmetic intensity.  Small matrices keep the plain scheme
+	// (their updates are latency-bound launches either way).
+	static int chol_outer_block(int n)
 	{
-		if (n % NB) return hipErrorInvalidValue;
-		for (int j0 = 0; j0 < n; j0 += NB)
+		static const int forced = [] {
+			const char* e = getenv("GPLE_CHOL_OUTER");
+			return e ? atoi(e) : -1;
+		}();
+		if (forced >= 0) return forced >= NB ? forced / NB * NB : 0;
+		return n >= 2048 ? 256 : 0;
+	}
+
+	static int panel_variant()
+	{
+		static const int v = [] {
+			const char* e = getenv("GPLE_PANEL_VARIANT");
+			return e ? atoi(e) : 0; // 1 = the column-split kernel: measured 23.6 us per panel against 20.5 (profiles/r02_notes.md)
+		}();
+		return v;
+	}
+	// panel steps of the block columns [j_begin, j_end) (multiples of NB; j_begin on an outer-block boundary or 0) of the n x n matrix
+	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end)
+	{
+		const int OB = chol_outer_block(n);
+		auto at = [&](int r, int c) { return A + r + static_cast<long>(c) * lda; };
+		// C(r0.., c0..) -= A(r0.., k0..k0+K) A(c0.., k0..k0+K)^T on the lower tiles of an m x ncols result whose (0,0) lies on the diagonal
+		auto syrk_update = [&](int r0, int m, int ncols, int k0, int K) -> hipError_t {
+			GemmDesc g{};
+			g.A = at(r0, k0), g.lda = lda, g.B = at(r0, k0), g.ldb = lda, g.C = at(r0, r0), g.ldc = lda;
+			g.M = m, g.N = ncols, g.K = K, g.batch = 1, g.alpha = -1.0, g.beta = 1.0, g.krange = K_FULL, g.lower_only = 1;
+			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
+			return launch_gemm(s, g, gemm_pick_tile(m, ncols, 1, true));
+		};
+		for (int j0 = j_begin; j0 < j_end; j0 += NB)
 		{
+			const int J0 = OB ? j0 / OB * OB : 0;                      // outer block column of this panel
+			const int Jend = OB ? (J0 + OB < n ? J0 + OB : n) : n;
 			const int m = n - j0; // rows of the panel including the diagonal block
 			const int below = m - NB;
 			const int nwg = below > 0 ? (below + PANEL_ROWS - 1) / PANEL_ROWS : 1;
-			hipLaunchKernelGGL(potrf_panel_kernel, dim3(nwg), dim3(PANEL_THREADS), 0, s, A + j0 + static_cast<long>(j0) * lda, lda, m, info, j0,
-				T + j0 + static_cast<long>(j0) * ldt, ldt);
-			if (below <= 0) break;
-			// trailing update: A22 -= P P^T (lower tiles)
-			double* P = A + (j0 + NB) + static_cast<long>(j0) * lda;
-			GemmDesc g{};
-			g.A = P, g.lda = lda, g.B = P, g.ldb = lda, g.C = A + (j0 + NB) + static_cast<long>(j0 + NB) * lda, g.ldc = lda;
-			g.M = below, g.N = below, g.K = NB, g.batch = 1, g.alpha = -1.0, g.beta = 1.0, g.krange = K_FULL, g.lower_only = 1;
-			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
-			const hipError_t e = launch_gemm(s, g, gemm_pick_tile(below, below, 1, true));
-			if (e != hipSuccess) return e;
+			if (panel_variant() == 1)
+				hipLaunchKernelGGL(potrf_panel16_kernel, dim3(nwg), dim3(P16_THREADS), 0, s, at(j0, j0), lda, m, info, j0, T + j0 + static_cast<long>(j0) * ldt, ldt);
+			else
+				hipLaunchKernelGGL(potrf_panel_kernel, dim3(nwg), dim3(PANEL_THREADS), 0, s, at(j0, j0), lda, m, info, j0, T + j0 + static_cast<long>(j0) * ldt, ldt);
+			// the rest of this block column: rows j0 + NB .. n, columns j0 + NB .. Jend
+			if (Jend - (j0 + NB) > 0)
+			{
+				const hipError_t e = syrk_update(j0 + NB, below, Jend - (j0 + NB), j0, NB);
+				if (e != hipSuccess) return e;
+			}
+			// last panel of an outer block: everything right of the block column, once, with K = the block's width
+			if (j0 + NB == Jend && n - Jend > 0)
+			{
+				const hipError_t e = syrk_update(Jend, n - Jend, n - Jend, J0, Jend - J0);
+				if (e != hipSuccess) return e;
+			}
 		}
+		return hipGetLastError();
+	}
+
+	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info)
+	{
+		if (n % NB) return hipErrorInvalidValue;
+		const hipError_t e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n);
+		if (e != hipSuccess) return e;
 		// the 64 x 64 inverses are only the leaves of the merge tree: one batched launch, off the factorisation's critical path
 		hipLaunchKernelGGL(trinv_diag_kernel, dim3(n / NB), dim3(64), 0, s, T, ldt, T, ldt);
 		return hipGetLastError();
@@ -311,6 +435,82 @@ namespace gple
 			blocks.swap(next);
 		}
 		return hipGetLastError();
+	}
+
+	// Smallest n for which the leading half's inverse goes to the side stream (two event hand-overs cost about 10 us)
+	static int chol_overlap_min_n()
+	{
+		static const int v = [] {
+			const char* e = getenv("GPLE_CHOL_OVERLAP_MIN_N");
+			return e ? atoi(e) : 1024;
+		}();
+		return v;
+	}
+	// split on an outer-block boundary near the middle: the columns left of H are final once their panels are done
+	static int chol_split_point(int n)
+	{
+		const int nblocks = n / NB, OB = chol_outer_block(n);
+		int H = nblocks / 2 * NB;
+		if (OB) H = (H + OB / 2) / OB * OB;
+		if (H <= 0 || H >= n) H = nblocks / 2 * NB;
+		return H;
+	}
+	size_t chol_inverse_work_doubles(int n)
+	{
+		// last merge: W = L21 T11, (n - H) x H; a tree over h columns needs at most h^2 / 4 (one pair spanning everything)
+		const size_t H = static_cast<size_t>(chol_split_point(n)), R = static_cast<size_t>(n) - H;
+		return R * H + H * H / 4 + R * R / 4 + static_cast<size_t>(n) * static_cast<size_t>(n) / 4 + 64; // last term: the unsplit path
+	}
+	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work)
+	{
+		if (n % NB) return hipErrorInvalidValue;
+		const int nblocks = n / NB;
+		if (n < chol_overlap_min_n() || nblocks < 4)
+		{
+			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info);
+			if (e != hipSuccess) return e;
+			return trtri_lower_from_diag(s, A, lda, T, ldt, n, work);
+		}
+		hipError_t e;
+		if (!ctx->side_stream)
+		{
+			if ((e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+			if ((e = hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming)) != hipSuccess) return e;
+			if ((e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming)) != hipSuccess) return e;
+		}
+		hipStream_t side = ctx->side_stream;
+		const int H = chol_split_point(n);
+		const size_t Hs = static_cast<size_t>(H), Rs = static_cast<size_t>(n - H);
+		double* w_top = work;                      // (n - H) x H
+		double* w_lead = w_top + Rs * Hs;          // tree of the leading half
+		double* w_trail = w_lead + Hs * Hs / 4;    // tree of the trailing half
+		// main stream: leading block columns
+		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, H)) != hipSuccess) return e;
+		if ((e = hipEventRecord(ctx->side_fork, s)) != hipSuccess) return e;
+		// side stream: T11 = L11^-1 and W = L21 T11, all inputs final
+		if ((e = hipStreamWaitEvent(side, ctx->side_fork, 0)) != hipSuccess) return e;
+		hipLaunchKernelGGL(trinv_diag_kernel, dim3(H / NB), dim3(64), 0, side, T, ldt, T, ldt);
+		if ((e = trtri_lower_from_diag(side, A, lda, T, ldt, H, w_lead)) != hipSuccess) return e;
+		{
+			GemmDesc g{};
+			g.A = A + H, g.lda = lda, g.B = T, g.ldb = ldt, g.C = w_top, g.ldc = n - H;
+			g.M = n - H, g.N = H, g.K = H, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
+			g.krange = K_GE_N, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
+			if ((e = launch_gemm(side, g, gemm_pick_tile(n - H, H, 1, true))) != hipSuccess) return e;
+		}
+		if ((e = hipEventRecord(ctx->side_join, side)) != hipSuccess) return e;
+		// main stream meanwhile: trailing block columns and their inverse
+		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, H, n)) != hipSuccess) return e;
+		double* T22 = T + H + static_cast<long>(H) * ldt;
+		hipLaunchKernelGGL(trinv_diag_kernel, dim3((n - H) / NB), dim3(64), 0, s, T22, ldt, T22, ldt);
+		if ((e = trtri_lower_from_diag(s, A + H + static_cast<long>(H) * lda, lda, T22, ldt, n - H, w_trail)) != hipSuccess) return e;
+		// join: T21 = -T22 W
+		if ((e = hipStreamWaitEvent(s, ctx->side_join, 0)) != hipSuccess) return e;
+		GemmDesc g{};
+		g.A = T22, g.lda = ldt, g.B = w_top, g.ldb = n - H, g.C = T + H, g.ldc = ldt;
+		g.M = n - H, g.N = H, g.K = n - H, g.batch = 1, g.alpha = -1.0, g.beta = 0.0;
+		g.krange = K_LE_M, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
+		return launch_gemm(s, g, gemm_pick_tile(n - H, H, 1, true));
 	}
 
 	hipError_t lauum_full(hipStream_t s, const double* T, long ldt, double* W, long ldw, int n)

@@ -73,6 +73,10 @@ namespace gple
 		bool owns_stream = false;
 		std::string last_error;
 		std::mutex mu; // guards last_error + scratch (predict calls may come from several host threads)
+		// second stream + two events for the part of a fit that does not sit on the factorisation's critical path (created on
+		// first use by chol_inverse_factor; the main stream waits for the side work before anything reads its results)
+		hipStream_t side_stream = nullptr;
+		hipEvent_t side_fork = nullptr, side_join = nullptr;
 		// pinned host block for scalar results
 		double* host_scalars = nullptr;
 		// tracing (gple_ctx_enable_timing): every timed interval takes an event pair from a free list and joins `pending`
@@ -141,6 +145,11 @@ namespace gple
 	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info);
 	// Completes T = L^-1 (lower) given its diagonal blocks; work: at least n*n/4 doubles.
 	hipError_t trtri_lower_from_diag(hipStream_t s, const double* L, long ldl, double* T, long ldt, int n, double* work);
+	// L = chol(A) and T = L^-1 in one go (what a fit needs): potrf_lower + trtri_lower_from_diag, with the inverse of the
+	// leading half (its merge tree and the first GEMM of the last merge, more than half of the tree's work) running on the
+	// context's side stream while the main stream factors the trailing half.  work: chol_inverse_work_doubles(n) doubles.
+	size_t chol_inverse_work_doubles(int n);
+	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work);
 	// W = T^T T (full symmetric n x n).
 	hipError_t lauum_full(hipStream_t s, const double* T, long ldt, double* W, long ldw, int n);
 } // namespace gple
