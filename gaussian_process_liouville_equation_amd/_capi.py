@@ -55,6 +55,11 @@ class Element(C.Structure):
     _fields_ = [("real", C.c_void_p), ("cplx", C.c_void_p)]
 
 
+class Points(C.Structure):
+    """gple_points: the selected phase-space points of one density-matrix element"""
+    _fields_ = [("r", C.POINTER(C.c_double)), ("rho", C.POINTER(C.c_double)), ("n", C.c_size_t)]
+
+
 class PredictScalars(C.Structure):
     _fields_ = [("error", C.c_double), ("error_derivative", C.c_double * 8)]
 
@@ -97,7 +102,7 @@ GPLE_SYMBOLS = [
     "real_gram", "complex_gram", "cutoff_factor", "predict_batch", "shard_bounds", "set_allgather_function", "real_predict_sharded", "complex_predict_sharded",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
-    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
+    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "pes_adiabatic", "evolve", "markov_chain", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
 ]
 
 
@@ -316,6 +321,42 @@ class Api:
         out = np.empty(2 * len(pts))
         self._check(self.lib.gple_predict_batch(self.ctx, arr, len(elements), _ptr(pts), idx.ctypes.data_as(C.POINTER(C.c_int)), len(pts), _ptr(out)))
         return out.view(np.complex128)
+
+    def _elements(self, fits):
+        arr = (Element * max(1, len(fits)))()
+        for i, f in enumerate(fits):
+            if f is not None:
+                setattr(arr[i], "real" if f.kind == "real" else "cplx", f.handle.value)
+        return arr
+
+    def pes_adiabatic(self, model, x):
+        """(M, 6): E0, E1, F00, F10, F11, NAC01 of Tully's model `model` (0 SAC, 1 DAC, 2 ECR) at positions x"""
+        x = _f64(x)
+        out = np.empty(6 * len(x))
+        self.lib.gple_pes_adiabatic.argtypes = [C.c_void_p, C.c_int, _dp, C.c_size_t, C.c_uint, _dp]
+        self._check(self.lib.gple_pes_adiabatic(self.ctx, int(model), _ptr(x), len(x), 0, _ptr(out)))
+        return out.reshape(-1, 6)
+
+    def evolve(self, fits, model, mass, dt, density):
+        """one tick of evolve(): fits = [fit(0,0) | None, fit(1,0) | None, fit(1,1) | None]; density = {(i, j): (r (n,2), rho (n,))}
+        -> the same structure one tick later"""
+        order = [(0, 0), (1, 0), (1, 1)]
+        rs = [np.ascontiguousarray(np.asarray(density[e][0], dtype=np.float64).reshape(-1, 2)).copy() for e in order]
+        rhos = [np.ascontiguousarray(np.asarray(density[e][1], dtype=np.complex128)).copy() for e in order]
+        pts = (Points * 3)()
+        for k in range(3):
+            pts[k].r, pts[k].rho, pts[k].n = _ptr(rs[k]), _ptr(rhos[k].view(np.float64)), len(rs[k])
+        self.lib.gple_evolve.argtypes = [C.c_void_p, C.POINTER(Element), C.c_int, C.c_double, C.c_double, C.POINTER(Points), C.c_uint]
+        self._check(self.lib.gple_evolve(self.ctx, self._elements(fits), int(model), float(mass), float(dt), pts, 0))
+        return {e: (rs[k], rhos[k]) for k, e in enumerate(order)}
+
+    def markov_chain(self, fit, num_steps, max_displacement, seed, r):
+        """Metropolis chains of all walkers on |cut-off prediction| of `fit`: (last points (n,2), acceptance ratio (n,))"""
+        r = np.ascontiguousarray(np.asarray(r, dtype=np.float64).reshape(-1, 2)).copy()
+        acc = np.empty(len(r))
+        self.lib.gple_markov_chain.argtypes = [C.c_void_p, C.POINTER(Element), C.c_size_t, C.c_double, C.c_ulonglong, _dp, C.c_size_t, _dp]
+        self._check(self.lib.gple_markov_chain(self.ctx, self._elements([fit]), int(num_steps), float(max_displacement), int(seed), _ptr(r), len(r), _ptr(acc)))
+        return r, acc
 
     def cutoff_factor(self, prediction, variance):
         is_c = np.iscomplexobj(prediction)

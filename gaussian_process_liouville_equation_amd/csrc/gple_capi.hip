@@ -1578,6 +1578,147 @@ extern "C"
 		return GPLE_OK;
 	}
 
+	// ---- step loop (N3) ----------------------------------------------------------------------------------------------------
+	int gple_pes_adiabatic(gple_ctx* ctx, int model, const double* x, size_t M, unsigned flags, double* out)
+	{
+		if (!ctx || model < 0 || model > 2 || (M && (!x || !out))) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		if (M == 0) return GPLE_OK;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		if (flags & GPLE_IO_DEVICE)
+		{
+			GPLE_HIP(ctx, launch_pes(st, x, (int)M, model, out));
+			return GPLE_OK;
+		}
+		Scratch xd(ctx), od(ctx);
+		GPLE_HIP(ctx, xd.get(M));
+		GPLE_HIP(ctx, od.get(6 * M));
+		GPLE_HIP(ctx, copy_in(st, xd.p, x, M, false));
+		GPLE_HIP(ctx, launch_pes(st, xd.p, (int)M, model, od.p));
+		GPLE_HIP(ctx, copy_out(st, out, od.p, 6 * M, false));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		return GPLE_OK;
+	}
+
+	// cut-off prediction of `el` at m device points -> out (m doubles, or m (re,im) pairs); out == nullptr on return means "0"
+	static int predict_element_cutoff(gple_ctx* ctx, const gple_element& el, const double* pts_dev, size_t m, double* out_dev)
+	{
+		if (el.real && el.cplx) return GPLE_ERR_BAD_ARG;
+		if (m == 0 || (!el.real && !el.cplx)) return GPLE_OK;
+		const FitCommon* f = el.real ? static_cast<const FitCommon*>(el.real) : static_cast<const FitCommon*>(el.cplx);
+		return predict_common(ctx, f, pts_dev, m, GPLE_IO_DEVICE, nullptr, nullptr, nullptr, out_dev, nullptr);
+	}
+
+	int gple_evolve(gple_ctx* ctx, const gple_element elements[3], int pes_model, double mass, double dt, gple_points density[3], unsigned flags)
+	{
+		if (!ctx || !elements || !density || pes_model < 0 || pes_model > 2 || !(mass > 0.0)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		int n[3];
+		size_t total = 0;
+		for (int e = 0; e < 3; ++e)
+		{
+			if (density[e].n > (1u << 28) || (density[e].n && (!density[e].r || !density[e].rho))) return GPLE_ERR_BAD_ARG;
+			n[e] = static_cast<int>(density[e].n);
+			total += density[e].n;
+		}
+		if (total == 0) return GPLE_OK;
+		const bool dev = flags & GPLE_IO_DEVICE;
+		long qoff[3][3], qlen[3];
+		int off[3];
+		evolve_layout(n, qoff, qlen, off);
+		hipStream_t st = ctx->stream;
+		Scratch r_old(ctx), rho_old(ctx), r_new(ctx), rho_new(ctx), cpl(ctx), q0(ctx), q1(ctx), q2(ctx), p0(ctx), p1(ctx), p2(ctx);
+		Scratch* q[3] = {&q0, &q1, &q2};
+		Scratch* pr[3] = {&p0, &p1, &p2};
+		{
+			std::lock_guard<std::mutex> lk(ctx->call_mu);
+			GPLE_HIP(ctx, hipSetDevice(ctx->device));
+			GPLE_HIP(ctx, r_old.get(2 * total));
+			GPLE_HIP(ctx, rho_old.get(2 * total));
+			GPLE_HIP(ctx, r_new.get(2 * total));
+			GPLE_HIP(ctx, rho_new.get(2 * total));
+			GPLE_HIP(ctx, cpl.get(total / 8 + 1));
+			for (int e = 0; e < 3; ++e)
+			{
+				GPLE_HIP(ctx, q[e]->get(2 * static_cast<size_t>(qlen[e]) + 2));
+				GPLE_HIP(ctx, pr[e]->get(2 * static_cast<size_t>(qlen[e]) + 2));
+				// the points of the three elements back to back
+				GPLE_HIP(ctx, copy_in(st, r_old.p + 2 * off[e], density[e].r, 2 * density[e].n, dev));
+				GPLE_HIP(ctx, copy_in(st, rho_old.p + 2 * off[e], density[e].rho, 2 * density[e].n, dev));
+			}
+			double* const qp[3] = {q0.p, q1.p, q2.p};
+			GPLE_HIP(ctx, launch_evolve_prepare(st, r_old.p, n, mass, dt, pes_model, r_new.p, reinterpret_cast<unsigned char*>(cpl.p), qp));
+		}
+		// one batched predict per density-matrix element over everything that was back-propagated into it
+		const double* pred[3] = {nullptr, nullptr, nullptr};
+		for (int e = 0; e < 3; ++e)
+		{
+			if (qlen[e] == 0 || (!elements[e].real && !elements[e].cplx)) continue;
+			if ((e == 1) != (elements[e].cplx != nullptr)) return GPLE_ERR_BAD_ARG; // (1,0) is the complex element, the diagonal ones are real
+			GPLE_TRY(predict_element_cutoff(ctx, elements[e], q[e]->p, static_cast<size_t>(qlen[e]), pr[e]->p));
+			pred[e] = pr[e]->p;
+		}
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		GPLE_HIP(ctx, launch_evolve_combine(st, r_old.p, r_new.p, rho_old.p, reinterpret_cast<const unsigned char*>(cpl.p), n, mass, dt, pes_model, pred, rho_new.p));
+		for (int e = 0; e < 3; ++e)
+		{
+			GPLE_HIP(ctx, copy_out(st, density[e].r, r_new.p + 2 * off[e], 2 * density[e].n, dev));
+			GPLE_HIP(ctx, copy_out(st, density[e].rho, rho_new.p + 2 * off[e], 2 * density[e].n, dev));
+		}
+		if (!dev) GPLE_HIP(ctx, hipStreamSynchronize(st));
+		return GPLE_OK;
+	}
+
+	int gple_markov_chain(gple_ctx* ctx, const gple_element* element, size_t num_steps, double max_displacement, unsigned long long seed, double* r,
+		size_t n, double* accept_ratio)
+	{
+		if (!ctx || !element || (n && !r) || n > (1u << 28) || (element->real && element->cplx)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		if (n == 0) return GPLE_OK;
+		hipStream_t st = ctx->stream;
+		const int ni = static_cast<int>(n), cplx = element->cplx ? 1 : 0;
+		const bool has_fit = element->real || element->cplx;
+		Scratch rd(ctx), rp(ctx), pred(ctx), weight(ctx), acc(ctx);
+		{
+			std::lock_guard<std::mutex> lk(ctx->call_mu);
+			GPLE_HIP(ctx, hipSetDevice(ctx->device));
+			GPLE_HIP(ctx, rd.get(2 * n));
+			GPLE_HIP(ctx, rp.get(2 * n));
+			GPLE_HIP(ctx, pred.get(2 * n));
+			GPLE_HIP(ctx, weight.get(n));
+			GPLE_HIP(ctx, acc.get(n / 2 + 1));
+			GPLE_HIP(ctx, copy_in(st, rd.p, r, 2 * n, false));
+			GPLE_HIP(ctx, hipMemsetAsync(acc.p, 0, (n / 2 + 1) * 8, st));
+		}
+		GPLE_TRY(predict_element_cutoff(ctx, *element, rd.p, n, pred.p));
+		{
+			std::lock_guard<std::mutex> lk(ctx->call_mu);
+			GPLE_HIP(ctx, launch_mc_weight(st, has_fit ? pred.p : nullptr, cplx, ni, weight.p)); // mc.cpp:131
+		}
+		for (size_t step = 0; step < num_steps; ++step)
+		{
+			{
+				std::lock_guard<std::mutex> lk(ctx->call_mu);
+				GPLE_HIP(ctx, launch_mc_propose(st, rd.p, ni, static_cast<unsigned>(step), seed, max_displacement, rp.p));
+			}
+			GPLE_TRY(predict_element_cutoff(ctx, *element, rp.p, n, pred.p));
+			std::lock_guard<std::mutex> lk(ctx->call_mu);
+			GPLE_HIP(ctx, launch_mc_accept(st, rd.p, rp.p, has_fit ? pred.p : nullptr, cplx, ni, static_cast<unsigned>(step), seed, weight.p,
+							  reinterpret_cast<unsigned*>(acc.p)));
+		}
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, copy_out(st, r, rd.p, 2 * n, false));
+		std::vector<unsigned> counts(accept_ratio ? n : 0);
+		if (accept_ratio) GPLE_HIP(ctx, hipMemcpyAsync(counts.data(), acc.p, n * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		if (accept_ratio)
+			for (size_t i = 0; i < n; ++i) accept_ratio[i] = num_steps ? static_cast<double>(counts[i]) / static_cast<double>(num_steps) : 0.0;
+		return GPLE_OK;
+	}
+
 	// loose_function (opt.cpp:441-482).  io = 0: host pointers; io = GPLE_IO_DEVICE: everything but x / value / grad is resident
 	// (lab = real parts of y_extra, the label vector of the real kernel's PredictiveKernel, opt.cpp:451)
 	static int loose_eval(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N, const double* X_extra,

@@ -245,6 +245,39 @@ typedef struct gple_element
 int gple_predict_batch(gple_ctx* ctx, const gple_element* elements, size_t n_elements, const double* points, const int* element_of_request,
 	size_t n_req, double* out);
 
+/* ---- the step loop around the GP (NumPES = 2, Dim = 1 as the reference instantiates it) ---------------- */
+typedef enum gple_pes_model /* pes.h:27-41; the reference's default TestModel is DAC */
+{
+	GPLE_PES_SAC = 0, /* Tully I:   simple avoided crossing            */
+	GPLE_PES_DAC = 1, /* Tully II:  dual avoided crossing               */
+	GPLE_PES_ECR = 2  /* Tully III: extended coupling with reflection  */
+} gple_pes_model;
+/* adiabatic_potential / adiabatic_force / adiabatic_coupling (pes.cpp:98-155) at M positions:
+ * out[6 i + {0..5}] = E0, E1, F(0,0), F(1,0), F(1,1), NAC(0,1). */
+int gple_pes_adiabatic(gple_ctx* ctx, int model, const double* x, size_t M, unsigned flags, double* out);
+
+/* One tick of evolve() (evolve.cpp:377-423): the points of the three density-matrix elements (0,0), (1,0), (1,1) are propagated
+ * (two half steps forward) and their densities rebuilt by the 3-branch back-propagation of non_adiabatic_evolve_predict
+ * (evolve.cpp:184-372), with `distribution` = the cut-off prediction of elements[e] (main.cpp:75-101; 0 for an element without
+ * a fit).  density[e].r (2 n_e, interleaved) and density[e].rho (n_e (re,im) pairs) are updated in place; host pointers, or
+ * device pointers with GPLE_IO_DEVICE.  All 8 * (n_0 + n_1 + n_2) back-propagated points are predicted in three batches. */
+typedef struct gple_points
+{
+	double* r;
+	double* rho;
+	size_t n;
+} gple_points;
+int gple_evolve(gple_ctx* ctx, const gple_element elements[3], int pes_model, double mass, double dt, gple_points density[3],
+	unsigned flags);
+
+/* generate_markov_chain (mc.cpp:118-165) for n walkers at once on the fitted distribution |cut-off prediction| of `element`:
+ * num_steps Metropolis steps with uniform displacements in [-max_displacement, max_displacement) per dimension; r (2n) holds
+ * the start points and receives the last points, accept_ratio (nullable, n) the accepted fraction per walker.  Random numbers:
+ * Philox4x32-10, counter (walker, step, block, 0), key = seed (the reference's generator is seeded from the clock and shared
+ * between threads, mc.cpp:17: no stream of it is reproducible).  Host pointers. */
+int gple_markov_chain(gple_ctx* ctx, const gple_element* element, size_t num_steps, double max_displacement, unsigned long long seed,
+	double* r, size_t n, double* accept_ratio);
+
 /* ---- negative_log_marginal_likelihood / predict (test/gpr.cpp:499-532, 654-706) -------------------- */
 /* Kernel = w_d^2 * Diag + w_g^2 * GaussianARD(weights), x = (w_d, w_g, a_x, a_p) with `a` the diagonal ARD
  * weights = inverse lengths (NOCROSS build, test/gpr.cpp:99,323-326). value = y^T K^-1 y / 2 + sum log L_ii;

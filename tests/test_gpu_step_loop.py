@@ -1,0 +1,101 @@
+"""GPU: the device step loop (gple_pes_adiabatic, gple_evolve, gple_markov_chain) against the numpy oracle
+of evolve.cpp / pes.cpp / mc.cpp (oracle/evolve_oracle.py), whose distribution function is the C++ oracle's predictor."""
+import numpy as np
+import pytest
+
+from gaussian_process_liouville_equation_amd import kernels as K
+from oracle import evolve_oracle as E
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+MASS, DT = 2000.0, 1.0
+TH, THC = [1.0, 0.7086, 0.7056, 1e-2], [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05]
+
+
+@pytest.mark.parametrize("model", [E.SAC, E.DAC, E.ECR])
+def test_pes_against_oracle(gpu, model):
+    x = np.concatenate([np.linspace(-12, -0.01, 200), np.linspace(0.01, 12, 200), [0.37, -2.5]])
+    got = gpu.pes_adiabatic(model, x)
+    e0, e1 = E.adiabatic_potential(x, model)
+    f00, f10, f11 = E.adiabatic_force(x, model)
+    ref = np.stack([e0, e1, f00, f10, f11, E.adiabatic_coupling_01(x, model)], axis=1)
+    scale = np.abs(ref).max(axis=0)
+    assert np.all(np.abs(got - ref) <= 1e-12 * scale + 1e-300)
+
+
+def _case(N, seed, x_centre=-1.5):
+    """a wave packet approaching the crossing: samples of all three elements with their (exact-like) densities"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    dens = {}
+    for e, (i, j) in enumerate(K.element_order(2)):
+        r = rng.normal([x_centre, 14.0], [0.7086, 0.7056], size=(N + 7 * e, 2))
+        g = np.exp(-0.5 * (((r[:, 0] - x_centre) / 0.7086) ** 2 + ((r[:, 1] - 14.0) / 0.7056) ** 2)) / (2 * np.pi * 0.7086 * 0.7056)
+        rho = g * (0.6, 0.3 * np.exp(0.4j * (r[:, 0] - x_centre)), 0.4)[e]
+        dens[(i, j)] = (r, rho.astype(complex))
+    return dens
+
+
+def _fits(api, dens):
+    return [api.real_fit(TH, *dens[(0, 0)], 0), api.complex_fit(THC, *dens[(1, 0)], 0), api.real_fit(TH, dens[(1, 1)][0], dens[(1, 1)][1], 0)]
+
+
+def _oracle_distribution(oracle, fits):
+    def distribution(pts, i, j):
+        f = fits[i * (i + 1) // 2 + j]
+        if f is None:
+            return np.zeros(len(pts), dtype=complex)
+        pred = oracle.complex_predict if i != j else oracle.real_predict
+        return np.asarray(pred(f, pts, want=("cutoff",))["cutoff"], dtype=complex)
+    return distribution
+
+
+@pytest.mark.parametrize("model,N", [(E.DAC, 150), (E.SAC, 90), (E.ECR, 60)])
+def test_evolve_tick_against_oracle(gpu, oracle, model, N):
+    dens = _case(N, 20240607 + N)
+    out = gpu.evolve(_fits(gpu, dens), model, MASS, DT, dens)
+    ref = E.evolve(dens, MASS, DT, _oracle_distribution(oracle, _fits(oracle, dens)), model)
+    for e in dens:
+        assert out[e][0].shape == ref[e][0].shape
+        assert np.abs(out[e][0] - ref[e][0]).max() <= 1e-12 * np.abs(ref[e][0]).max()   # coordinates: pure propagation
+        scale = max(np.abs(ref[e][1]).max(), np.abs(dens[e][1]).max())
+        assert np.abs(out[e][1] - ref[e][1]).max() <= 1e-8 * scale, e                     # densities: through two GP predicts
+        assert np.abs(out[e][1] - dens[e][1]).max() > 1e-6 * scale                        # the tick did something
+    # the diagonal elements of a density matrix stay real under the back-propagation of real diagonal predictions
+    assert np.abs(out[(0, 0)][1].imag).max() <= 1e-9 * np.abs(out[(0, 0)][1]).max()
+
+
+def test_evolve_with_unpopulated_elements(gpu, oracle):
+    """only rho_00 populated (the reference's initial state, main.cpp:38): absent elements predict 0 (main.cpp:86-88) and
+    empty point sets stay empty"""
+    dens = _case(80, 5)
+    dens[(1, 0)] = (np.zeros((0, 2)), np.zeros(0, complex))
+    dens[(1, 1)] = (np.zeros((0, 2)), np.zeros(0, complex))
+    fits_g = [gpu.real_fit(TH, *dens[(0, 0)], 0), None, None]
+    fits_o = [oracle.real_fit(TH, *dens[(0, 0)], 0), None, None]
+    out = gpu.evolve(fits_g, E.DAC, MASS, DT, dens)
+    ref = E.evolve(dens, MASS, DT, _oracle_distribution(oracle, fits_o), E.DAC)
+    assert len(out[(1, 0)][0]) == 0 and len(out[(1, 1)][1]) == 0
+    assert np.abs(out[(0, 0)][0] - ref[(0, 0)][0]).max() <= 1e-12 * np.abs(ref[(0, 0)][0]).max()
+    assert np.abs(out[(0, 0)][1] - ref[(0, 0)][1]).max() <= 1e-8 * np.abs(ref[(0, 0)][1]).max()
+
+
+def test_metropolis_chains_against_oracle(gpu, oracle):
+    """same Philox stream, same decisions: every walker ends where the oracle's walker ends"""
+    dens = _case(200, 11, x_centre=-10.0)
+    X, rho = dens[(0, 0)]
+    fg, fo = gpu.real_fit(TH, X, rho, 0), oracle.real_fit(TH, X, rho, 0)
+    start = X[:120]
+    rg, ag = gpu.markov_chain(fg, 25, 0.3, 0xC0FFEE1234, start)
+    ro, ao = E.generate_markov_chain(25, lambda pts, i, j: oracle.real_predict(fo, pts, want=("cutoff",))["cutoff"], 0.3, 0, 0, start, 0xC0FFEE1234)
+    same = np.abs(rg - ro).max(axis=1) <= 1e-12
+    assert same.mean() >= 0.98, same.mean()  # a decision can flip only where new/old sits within rounding of the random number
+    assert np.abs(ag[same] - ao[same]).max() <= 1e-15 and 0.05 < ag.mean() < 0.95
+    # complex element: weights are the modulus of the complex cut-off prediction
+    Xc, rc = dens[(1, 0)]
+    fgc, foc = gpu.complex_fit(THC, Xc, rc, 0), oracle.complex_fit(THC, Xc, rc, 0)
+    rg, ag = gpu.markov_chain(fgc, 10, 0.2, 7, Xc[:64])
+    ro, ao = E.generate_markov_chain(10, lambda pts, i, j: oracle.complex_predict(foc, pts, want=("cutoff",))["cutoff"], 0.2, 1, 0, Xc[:64], 7)
+    assert (np.abs(rg - ro).max(axis=1) <= 1e-12).mean() >= 0.95
+    # no steps: nothing moves
+    r0, a0 = gpu.markov_chain(fg, 0, 0.3, 1, start)
+    assert np.array_equal(r0, start) and np.all(a0 == 0)

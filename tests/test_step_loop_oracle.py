@@ -1,0 +1,69 @@
+"""CPU: the numpy oracle of the step loop (oracle/evolve_oracle.py: Tully models, MQCLE back-propagation, Philox Metropolis)
+against facts that do not depend on it: eigenvalues / Hellmann-Feynman forces of the diabatic matrix, the published
+known-answer vectors of Philox4x32-10, and limits in which the back-propagation formula collapses."""
+import numpy as np
+import pytest
+
+from oracle import evolve_oracle as E
+
+
+@pytest.mark.parametrize("model", [E.SAC, E.DAC, E.ECR])
+def test_adiabatic_representation(model):
+    x = np.concatenate([np.linspace(-6, -0.05, 40), np.linspace(0.05, 6, 40)])
+    v00, v01, v11 = E.diabatic_potential(x, model)
+    e0, e1 = E.adiabatic_potential(x, model)
+    for i in range(len(x)):
+        w = np.linalg.eigvalsh(np.array([[v00[i], v01[i]], [v01[i], v11[i]]]))
+        assert abs(w[0] - e0[i]) <= 1e-15 + 1e-13 * abs(w[0]) and abs(w[1] - e1[i]) <= 1e-15 + 1e-13 * abs(w[1])
+    # diabatic force = -dV/dx; diagonal adiabatic force = -dE/dx (Hellmann-Feynman)
+    h = 1e-6
+    for k, (f, vp, vm) in enumerate(zip(E.diabatic_force(x, model), E.diabatic_potential(x + h, model), E.diabatic_potential(x - h, model))):
+        assert np.abs(f + (vp - vm) / (2 * h)).max() <= 1e-8, k
+    f00, f10, f11 = E.adiabatic_force(x, model)
+    ep, em = E.adiabatic_potential(x + h, model), E.adiabatic_potential(x - h, model)
+    assert np.abs(f00 + (ep[0] - em[0]) / (2 * h)).max() <= 1e-8 and np.abs(f11 + (ep[1] - em[1]) / (2 * h)).max() <= 1e-8
+    assert np.allclose(np.abs(E.adiabatic_coupling_01(x, model)), np.abs(f10 / (e1 - e0)), rtol=1e-14)
+    assert E.is_coupling(x, 10.0 + 0 * x, 2000.0, 1.0, model).all()  # CouplingCriterion = 0 with >=
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32 with 10 rounds"""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, out in kat:
+        assert tuple(int(v) for v in E.philox4x32(np.array(ctr), key)) == out
+    u0, u1, u2 = E.philox_uniform(np.arange(4000), 3, 0x1234567890ABCDEF)
+    for u in (u0, u1, u2):
+        assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02 and abs(u.var() - 1 / 12) < 0.01
+    assert abs(np.corrcoef(u0, u2)[0, 1]) < 0.05
+
+
+def test_back_propagation_preserves_a_stationary_density():
+    """If every element's distribution is constant in phase space and the exact densities equal those constants, the three
+    branches recombine to the same constants wherever the coupling vanishes (SAC far from the crossing): the combination
+    coefficients of evolve.cpp:339-367 sum to the identity."""
+    rng = np.random.default_rng(1)
+    r = np.stack([rng.uniform(9.0, 11.0, 50), rng.uniform(8.0, 12.0, 50)], axis=1)  # |x| ~ 10: V01 = 0.005 exp(-100) ~ 0
+    const = {(0, 0): 0.7, (1, 0): 0.2 - 0.1j, (1, 1): 0.3}
+    dist = lambda pts, i, j: np.full(len(pts), const[(i, j)], dtype=complex)
+    dens = {e: (r.copy(), np.full(len(r), c, dtype=complex)) for e, c in const.items()}
+    out = E.evolve(dens, 2000.0, 0.5, dist, E.SAC)
+    for e, c in const.items():
+        rn, rho = out[e]
+        assert np.all(np.isfinite(rn)) and np.abs(rn - r).max() > 1e-4  # the points moved
+        if e == (1, 0):  # the coherence picks up exp(-i (E1 - E0) dt) relative to a constant field: compare moduli
+            assert np.abs(np.abs(rho) - abs(c)).max() <= 1e-9
+        else:
+            assert np.abs(rho - c).max() <= 1e-9
+
+
+def test_metropolis_samples_the_target():
+    """chains on a Gaussian target |rho| reproduce its mean and variance; the acceptance ratio falls with the step size"""
+    target = lambda pts, i, j: np.exp(-0.5 * (((pts[:, 0] + 10.0) / 0.7) ** 2 + ((pts[:, 1] - 14.0) / 0.5) ** 2)) + 0j
+    start = np.tile([-10.0, 14.0], (3000, 1))
+    r, acc = E.generate_markov_chain(60, target, 0.8, 0, 0, start, seed=42)
+    assert abs(r[:, 0].mean() + 10.0) < 0.05 and abs(r[:, 1].mean() - 14.0) < 0.05
+    assert abs(r[:, 0].std() - 0.7) < 0.06 and abs(r[:, 1].std() - 0.5) < 0.05
+    _, acc_big = E.generate_markov_chain(60, target, 3.0, 0, 0, start, seed=42)
+    assert 0.15 < acc.mean() < 0.9 and acc_big.mean() < acc.mean()
