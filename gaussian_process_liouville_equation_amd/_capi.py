@@ -55,6 +55,76 @@ class Element(C.Structure):
     _fields_ = [("real", C.c_void_p), ("cplx", C.c_void_p)]
 
 
+class OptOptions(C.Structure):
+    _fields_ = [("xtol_rel", C.c_double), ("ftol_rel", C.c_double), ("xtol_abs", C.c_double), ("ftol_abs", C.c_double),
+                ("initial_step", C.c_double), ("max_eval", C.c_int)]
+
+
+OBJECTIVE_FN = C.CFUNCTYPE(C.c_double, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)           # nlopt_func
+CONSTRAINT_FN = C.CFUNCTYPE(None, C.c_uint, C.POINTER(C.c_double), C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)  # nlopt_mfunc
+
+
+def _opt_options(maxeval=0, initial_step=0.5):
+    return OptOptions(1e-5, 1e-5, 1e-15, 1e-15, initial_step, int(maxeval or 0))
+
+
+def minimize_neldermead(lib, fun, x0, lb, ub, maxeval=0):
+    """the library's own Nelder-Mead (gple_minimize_neldermead) on a Python objective fun(x list) -> float; (x, f, n_eval)"""
+    n = len(x0)
+    cb = OBJECTIVE_FN(lambda nn, xp, gp, data: float(fun([xp[i] for i in range(nn)])))
+    x, lbv, ubv = _f64(x0).copy(), _f64(lb), _f64(ub)
+    f, ne = C.c_double(), C.c_int()
+    lib.gple_minimize_neldermead.argtypes = [OBJECTIVE_FN, C.c_void_p, C.c_uint, _dp, _dp, C.POINTER(OptOptions), _dp, _dp, C.POINTER(C.c_int)]
+    st = lib.gple_minimize_neldermead(cb, None, n, _ptr(lbv), _ptr(ubv), C.byref(_opt_options(maxeval)), _ptr(x), C.cast(C.byref(f), _dp), C.byref(ne))
+    if st != GPLE_OK:
+        raise GpleError(f"gple_minimize_neldermead: status {st}")
+    return list(x), f.value, ne.value
+
+
+def minimize_auglag_eq(lib, fun, constraint, m, x0, lb, ub, maxeval=0):
+    """the library's augmented-Lagrangian search: fun(x, want_grad) -> (f, grad or None); constraint(x, want_grad) ->
+    (h (m,), grad (m*n,) row-major or None); returns (x, f, n_eval)"""
+    n = len(x0)
+
+    def f_cb(nn, xp, gp, data):
+        v, g = fun([xp[i] for i in range(nn)], bool(gp))
+        if gp:
+            for i in range(nn):
+                gp[i] = g[i]
+        return float(v)
+
+    def h_cb(mm, rp, nn, xp, gp, data):
+        h, g = constraint([xp[i] for i in range(nn)], bool(gp))
+        for i in range(mm):
+            rp[i] = h[i]
+        if gp:
+            for i in range(mm * nn):
+                gp[i] = g[i]
+
+    fc, hc = OBJECTIVE_FN(f_cb), CONSTRAINT_FN(h_cb)
+    x, lbv, ubv = _f64(x0).copy(), _f64(lb), _f64(ub)
+    f, ne = C.c_double(), C.c_int()
+    lib.gple_minimize_auglag_eq.argtypes = [OBJECTIVE_FN, C.c_void_p, CONSTRAINT_FN, C.c_void_p, C.c_uint, C.c_uint, _dp, _dp, C.POINTER(OptOptions), _dp, _dp,
+                                            C.POINTER(C.c_int)]
+    st = lib.gple_minimize_auglag_eq(fc, None, hc, None, m, n, _ptr(lbv), _ptr(ubv), C.byref(_opt_options(maxeval)), _ptr(x), C.cast(C.byref(f), _dp), C.byref(ne))
+    if st != GPLE_OK:
+        raise GpleError(f"gple_minimize_auglag_eq: status {st}")
+    return list(x), f.value, ne.value
+
+
+def objective_minimize_neldermead(lib, objectives, x0, lb, ub, maxeval=0):
+    """gple_objective_minimize_neldermead over resident objectives (same data, different contexts): vertices evaluated concurrently"""
+    n = len(x0)
+    arr = (C.c_void_p * len(objectives))(*[o.handle.value for o in objectives])
+    x, lbv, ubv = _f64(x0).copy(), _f64(lb), _f64(ub)
+    f, ne = C.c_double(), C.c_int()
+    lib.gple_objective_minimize_neldermead.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, _dp, _dp, C.POINTER(OptOptions), _dp, _dp, C.POINTER(C.c_int)]
+    st = lib.gple_objective_minimize_neldermead(arr, len(objectives), n, _ptr(lbv), _ptr(ubv), C.byref(_opt_options(maxeval)), _ptr(x), C.cast(C.byref(f), _dp), C.byref(ne))
+    if st != GPLE_OK:
+        raise GpleError(f"gple_objective_minimize_neldermead: status {st}")
+    return list(x), f.value, ne.value
+
+
 class Points(C.Structure):
     """gple_points: the selected phase-space points of one density-matrix element"""
     _fields_ = [("r", C.POINTER(C.c_double)), ("rho", C.POINTER(C.c_double)), ("n", C.c_size_t)]
@@ -102,7 +172,7 @@ GPLE_SYMBOLS = [
     "real_gram", "complex_gram", "cutoff_factor", "predict_batch", "shard_bounds", "set_allgather_function", "real_predict_sharded", "complex_predict_sharded",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
-    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "pes_adiabatic", "evolve", "markov_chain", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
+    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "minimize_neldermead", "objective_minimize_neldermead", "minimize_auglag_eq", "pes_adiabatic", "evolve", "markov_chain", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
 ]
 
 

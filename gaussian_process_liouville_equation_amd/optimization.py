@@ -174,6 +174,30 @@ def _auglag_eq(fun, constraint, m, x0, lb, ub, max_outer=20, inner_maxiter=100):
     return list(c.expand(best[0])), float(best[1]), c.numevals
 
 
+def _native_nelder_mead(api, fun, resident, x0, lb, ub, maxeval=None):
+    """The library's own Nelder-Mead (gple_objective_minimize_neldermead on the resident objective when there is one: the
+    whole search then runs inside the library; otherwise gple_minimize_neldermead calling back into `fun`)."""
+    from . import _capi as c
+    lib = getattr(api, "lib", None)
+    if lib is None or not hasattr(lib, "gple_minimize_neldermead"):  # the oracle binding of the CPU tests has no searches
+        return _nelder_mead(fun, x0, lb, ub, maxeval)
+    if resident is not None and hasattr(resident, "handle"):
+        return c.objective_minimize_neldermead(lib, [resident], x0, lb, ub, maxeval or 0)
+    return c.minimize_neldermead(lib, lambda x: fun(list(x), []), x0, lb, ub, maxeval or 0)
+
+
+def _native_auglag_eq(fun, constraint, m, x0, lb, ub):
+    """The library's augmented-Lagrangian search (gple_minimize_auglag_eq) over Python objective / constraint callbacks."""
+    from . import _capi as c
+    from . import load_library
+
+    def f(x, want_grad):
+        g = [0.0] * len(x) if want_grad else []
+        return fun(list(x), g), g
+
+    return c.minimize_auglag_eq(load_library(), f, constraint, m, x0, lb, ub)
+
+
 class Optimization:
     """opt.h:16-131.  `optimize(density, extra_points)` refits every element's hyperparameters for one time step and
     returns (error, steps per stage, OptimizationType); `get_parameters()` then feeds `TrainingKernels` / the predictors.
@@ -184,7 +208,11 @@ class Optimization:
     Result = tuple
 
     def __init__(self, sigma_r0, rmin, rmax, mass, InitialTotalEnergy, InitialPurity, potential=None, api=None, num_pes=None,
-                 local_maxeval=None):
+                 local_maxeval=None, searches="scipy"):
+        # searches: "scipy" = SciPy's Nelder-Mead / SLSQP behind the reference's control flow; "native" = the library's own
+        # Nelder-Mead and augmented Lagrangian (csrc/gple_opt.hip, include/gple.h) — no SciPy in the local stages
+        assert searches in ("scipy", "native")
+        self.searches = searches
         self.TotalEnergy, self.Purity = float(InitialTotalEnergy), float(InitialPurity)
         self.mass, self.potential = float(np.ravel(mass)[0]), potential
         self.api = api or K.default_api()
@@ -232,6 +260,8 @@ class Optimization:
                     obj = lambda x, g: K.loose_function_global_wrapper(x, g, etp, api=one_api)
                     return _direct(obj, params[e], K.local_parameter_to_global(lb), K.local_parameter_to_global(ub))
                 obj = lambda x, g: K.loose_function(x, g, etp, api=one_api)
+                if self.searches == "native":
+                    return _native_nelder_mead(one_api, obj, etp[2], params[e], lb, ub, self.local_maxeval)
                 return _nelder_mead(obj, params[e], lb, ub, self.local_maxeval)
             except (ArithmeticError, ValueError):  # opt.cpp:555-565: a failed search keeps what it had
                 return params[e], 0.0, 0
@@ -254,7 +284,7 @@ class Optimization:
         m = 3 if Purity > 0 else 2
         obj = lambda x, g: K.diagonal_loose(x, g, (TrainingSets, ExtraTrainingSets, self._objectives), api=self.api, num_pes=n)
         con = lambda x, want: K.diagonal_constraints(m, x, want, (TrainingSets, Energies, self.TotalEnergy, Purity), api=self.api, num_pes=n)
-        x, err, steps = _auglag_eq(obj, con, m, x0, self._stack(0, True), self._stack(1, True))
+        x, err, steps = (_native_auglag_eq if self.searches == "native" else _auglag_eq)(obj, con, m, x0, self._stack(0, True), self._stack(1, True))
         for i in range(n):
             params[(i, i)] = list(x[i * K.REAL_NPARAM:(i + 1) * K.REAL_NPARAM])
         return err, [steps]
@@ -265,7 +295,7 @@ class Optimization:
         x0 = K.construct_combined_parameters(params, n)
         obj = lambda x, g: K.full_loose(x, g, (TrainingSets, ExtraTrainingSets, self._objectives), api=self.api, num_pes=n)
         con = lambda x, want: K.full_constraints(x, want, (TrainingSets, Energies, self.TotalEnergy, self.Purity), api=self.api, num_pes=n)
-        x, err, steps = _auglag_eq(obj, con, 3, x0, self._stack(0, False), self._stack(1, False))
+        x, err, steps = (_native_auglag_eq if self.searches == "native" else _auglag_eq)(obj, con, 3, x0, self._stack(0, False), self._stack(1, False))
         params.update(K.construct_all_parameters(x, n))
         return err, [steps]
 

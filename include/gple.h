@@ -245,6 +245,28 @@ typedef struct gple_element
 int gple_predict_batch(gple_ctx* ctx, const gple_element* elements, size_t n_elements, const double* points, const int* element_of_request,
 	size_t n_req, double* out);
 
+/* ---- the searches of Optimization (opt.cpp:333-355, 517-587, 730-800, 940-1015) ------------------------- */
+/* Own implementations behind NLopt's C callback ABIs (NLopt is un-vendored and absent): the reference's objective and
+ * constraint callbacks plug in unchanged.  options == NULL: the reference's settings (opt.cpp:344-346). */
+typedef double (*gple_objective_fn)(unsigned n, const double* x, double* grad, void* data);                                /* nlopt_func  */
+typedef void (*gple_constraint_fn)(unsigned m, double* result, unsigned n, const double* x, double* grad, void* data); /* nlopt_mfunc */
+typedef struct gple_opt_options
+{
+	double xtol_rel, ftol_rel, xtol_abs, ftol_abs; /* 1e-5, 1e-5, 1e-15, 1e-15 */
+	double initial_step;                           /* 0.5 (derivative-free search only) */
+	int max_eval;                                  /* 0: 400 per free dimension (Nelder-Mead) / 2000 (augmented Lagrangian) */
+} gple_opt_options;
+/* LN_NELDERMEAD stand-in inside the box [lb, ub] (NULL = unbounded; lb[i] == ub[i] fixes x_i).  x: start point in, minimiser out. */
+int gple_minimize_neldermead(gple_objective_fn f, void* data, unsigned n, const double* lb, const double* ub, const gple_opt_options* options,
+	double* x, double* fmin, int* n_eval);
+/* The same search on the resident objective (loose_function, opt.cpp:441-482; n = 4 or 8) with the simplex vertices evaluated
+ * concurrently: objectives[k] are handles on the SAME data created on different contexts (one HIP stream each). */
+int gple_objective_minimize_neldermead(gple_objective* const* objectives, size_t n_objectives, size_t n, const double* lb, const double* ub,
+	const gple_opt_options* options, double* x, double* fmin, int* n_eval);
+/* AUGLAG_EQ stand-in: minimise f subject to h(x) = 0 (m equality constraints, row-major m x n gradient) inside the box. */
+int gple_minimize_auglag_eq(gple_objective_fn f, void* fdata, gple_constraint_fn h, void* hdata, unsigned m, unsigned n, const double* lb,
+	const double* ub, const gple_opt_options* options, double* x, double* fmin, int* n_eval);
+
 /* ---- the step loop around the GP (NumPES = 2, Dim = 1 as the reference instantiates it) ---------------- */
 typedef enum gple_pes_model /* pes.h:27-41; the reference's default TestModel is DAC */
 {

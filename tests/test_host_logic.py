@@ -179,3 +179,25 @@ def test_oracle_complex_kernel_base_against_fixture(oracle):
         g = load_golden(name)
         Ko, Kto = oracle.complex_gram(g["theta"], g["X"], g["X"], True)
         assert parity.rel(Ko, g["K"]) <= 8 * parity.EPS and parity.rel(Kto, g["Kt"]) <= 8 * parity.EPS
+
+
+def test_native_searches_on_analytic_problems():
+    """csrc/gple_opt.hip (N2): the library's own Nelder-Mead and augmented Lagrangian behind NLopt's callback ABIs — host code,
+    so it runs without a GPU.  Rosenbrock in a box, a fixed coordinate, an active bound, an equality-constrained quadratic."""
+    import gaussian_process_liouville_equation_amd as pkg
+    from gaussian_process_liouville_equation_amd import _capi as c
+    lib = pkg.load_library()
+    rosen = lambda x: 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2
+    x, f, n = c.minimize_neldermead(lib, rosen, [-1.2, 1.0], [-5, -5], [5, 5], maxeval=2000)
+    assert np.allclose(x, [1, 1], atol=1e-4) and f < 1e-9 and 50 < n <= 2000
+    x, f, _ = c.minimize_neldermead(lib, rosen, [-1.2, 1.0, 3.0], [-5, -5, 3.0], [0.5, 5, 3.0], maxeval=2000)
+    assert abs(x[0] - 0.5) < 1e-6 and abs(x[1] - 0.25) < 1e-3 and x[2] == 3.0  # active bound, fixed coordinate
+    fun = lambda x, g: (x[0] ** 2 + 2 * x[1] ** 2, [2 * x[0], 4 * x[1]])
+    con = lambda x, g: ([x[0] + x[1] - 1.0], [1.0, 1.0])
+    x, f, _ = c.minimize_auglag_eq(lib, fun, con, 1, [3.0, -1.0], [-5, -5], [5, 5])
+    assert abs(x[0] + x[1] - 1.0) < 1e-6 and abs(f - 2.0 / 3.0) < 1e-5 and np.allclose(x, [2 / 3, 1 / 3], atol=2e-3)
+    # two constraints pin the point: min |x|^2 s.t. x0 + x1 + x2 = 1, x0 - x2 = 0.2
+    fun3 = lambda x, g: (sum(v * v for v in x), [2 * v for v in x])
+    con3 = lambda x, g: ([x[0] + x[1] + x[2] - 1.0, x[0] - x[2] - 0.2], [1.0, 1.0, 1.0, 1.0, 0.0, -1.0])
+    x, f, _ = c.minimize_auglag_eq(lib, fun3, con3, 2, [0.0, 0.0, 0.0], [-2] * 3, [2] * 3)
+    assert np.allclose(x, [1 / 3 + 0.1, 1 / 3, 1 / 3 - 0.1], atol=2e-3)

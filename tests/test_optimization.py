@@ -30,10 +30,10 @@ def _density(n, seed=5, offdiag=False):
             (1, 1): (r11, (0.2 * _wigner(r11)).astype(complex))}
 
 
-def _run(api, n, offdiag=False):
+def _run(api, n, offdiag=False, searches="scipy"):
     density = _density(n, offdiag=offdiag)
     e0 = O.calculate_total_energy_average_one_surface(density[(0, 0)], MASS, 0)
-    opt = O.Optimization(SIGMA, (-6.0, 4.0), (6.0, 16.0), MASS, e0, 1.0, api=api, local_maxeval=150)
+    opt = O.Optimization(SIGMA, (-6.0, 4.0), (6.0, 16.0), MASS, e0, 1.0, api=api, local_maxeval=150, searches=searches)
     start = K.loose_function(opt.InitialKernelParameter, [], (density[(0, 0)], (np.zeros((0, 2)), np.zeros(0, complex))), api=api)
     err, steps, kind = opt.optimize(density, {})
     return opt, density, start, err, steps, kind
@@ -118,6 +118,48 @@ def test_optimization_driver_with_offdiagonal_element(gpu):
     ks = K.TrainingKernels(p, K.construct_training_sets(density), False, True, False, api=gpu)
     assert abs(ks.calculate_population() - 1.0) < 2 * O.AverageTolerance
     assert abs(ks.calculate_purity() - 1.0) < 2 * O.AverageTolerance
+
+
+@pytest.mark.gpu
+def test_optimization_with_the_native_searches(gpu):
+    """N2 on the native side: the library's own Nelder-Mead (on the resident objective, inside the library) and augmented
+    Lagrangian drive the same three stages; the fit they find is as good as the SciPy-driven one and meets the constraints"""
+    opt, density, start, err, steps, kind = _run(gpu, 200, offdiag=True, searches="native")
+    _, _, _, err_scipy, _, _ = _run(gpu, 200, offdiag=True, searches="scipy")
+    assert all(s > 0 for s in steps) and math.isfinite(err)
+    assert err <= 1.5 * err_scipy + 1e-6  # no worse than the stand-in searches, within the slack two local searches differ by
+    p = opt.get_parameters()
+    lb, ub = opt.get_lower_bounds(), opt.get_upper_bounds()
+    for e in p:
+        for v, l, u in zip(p[e][1:], lb[e][1:], ub[e][1:]):
+            assert l - 1e-12 <= v <= u + 1e-12
+    ks = K.TrainingKernels(p, K.construct_training_sets(density), False, True, False, api=gpu)
+    assert abs(ks.calculate_population() - 1.0) < 2 * O.AverageTolerance
+    assert abs(ks.calculate_purity() - 1.0) < 2 * O.AverageTolerance
+
+
+@pytest.mark.gpu
+def test_concurrent_vertex_evaluation_gives_the_sequential_result(gpu):
+    """gple_objective_minimize_neldermead with three resident objectives (three contexts = three HIP streams): the simplex
+    vertices are evaluated concurrently, the decisions are those of the sequential search -> identical minimiser"""
+    import gaussian_process_liouville_equation_amd as pkg
+    from gaussian_process_liouville_equation_amd import _capi as c
+    from tests import parity
+    X, y, _ = parity.synthetic_real(400, 1, 77)
+    rng = np.random.default_rng(3)
+    Xe = X[np.arange(1200) % 400] + rng.normal(0, 0.5, size=(1200, 2))
+    ye = np.exp(-0.5 * (((Xe[:, 0] + 10.0) / 0.7086) ** 2 + ((Xe[:, 1] - 14.112) / 0.7056) ** 2)) / (2 * np.pi * 0.7086 * 0.7056)
+    apis = [gpu, pkg.open_api(0), pkg.open_api(0)]
+    objs = [a.objective(X, y.astype(complex), Xe, ye.astype(complex)) for a in apis]
+    x0, lb, ub = [1.0, 1.5, 0.4, 1e-2], [1.0, 0.01, 0.01, 1e-2], [1.0, 12.0, 12.0, 1e-2]
+    x1, f1, n1 = c.objective_minimize_neldermead(gpu.lib, objs[:1], x0, lb, ub, 300)
+    x3, f3, n3 = c.objective_minimize_neldermead(gpu.lib, objs, x0, lb, ub, 300)
+    assert x1 == x3 and f1 == f3 and n1 == n3
+    assert f1 < objs[0](x0, want_grad=False)[0] and lb[1] <= x1[1] <= ub[1] and x1[0] == 1.0 and x1[3] == 1e-2
+    for o in objs:
+        o.release()
+    for a in apis[1:]:
+        a.close()
 
 
 @pytest.mark.gpu
