@@ -276,6 +276,283 @@ namespace gple
 			if (lane < 16) q[static_cast<long>(g) * qstride + m0 + w * 16 + lane] = rsq; // partial sums of tile group g
 		}
 
+		// ---- register-blocked variant ------------------------------------------------------------------------------------
+		// rownorm_kernel gives every wave 16 rows x all 256 columns: 1 + 16 operand fragments from LDS per 16 MFMAs.  The bare
+		// MFMA loop with that operand pattern sustains 72.6 TFLOP/s against 78.4 from registers (probes/mfma_f64_sustained):
+		// the LDS operand reads cost ~8 %.  Here a wave owns AF x BF fragments (AF * BF = 16 accumulators as before): AF + BF
+		// reads per 16 MFMAs — 8 for 4 x 4, 10 for 2 x 8.  The 8 waves form a (128 / (16 AF)) x WN grid over the same 128 x 256
+		// workgroup tile; a wave's BF column blocks are interleaved (block wn + WN t), so that inside the diagonal 256-block,
+		// where the column blocks left of k drop out one per k-step, all waves keep the same number of live blocks (+-1).
+		// The live range depends on the wave's column index, which must be a compile-time constant for the skipping to stay
+		// straight-line code (branches around live accumulators make hipcc spill): the tile loop is instantiated per wn.
+		template <int AF, int BF, int WNI>
+		__device__ __forceinline__ void rownorm2_tiles(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt, int n_total,
+			double* lds, double (&rsq)[AF], int m0, int wm)
+		{
+			constexpr int KB = 16, TM = BM, NT = NTHREADS, WN = 16 / BF;
+			constexpr int ASr = TM + 16;
+			constexpr int ASL = KB * ASr, BSL = KB * BS;
+			constexpr int NA = TM * KB / 2 / NT, NBv = BN * KB / 2 / NT;
+			double* const As = lds;
+			double* const Bs = lds + 2 * ASL;
+			const int t = threadIdx.x, lane = t & 63;
+			const int fk = lane >> 4, fr = lane & 15;
+			const int ntiles = n_total / BN;
+			d2 areg[NA], breg[NBv];
+			auto load_ab = [&](int n0, int k0) {
+				const double* __restrict__ abase = Ks + m0 + static_cast<long>(k0) * rows;
+#pragma unroll
+				for (int qq = 0; qq < NA; ++qq)
+				{
+					const int i = t + NT * qq;
+					const int r2 = (i % (TM / 2)) * 2, k = i / (TM / 2);
+					areg[qq] = *reinterpret_cast<const d2*>(abase + r2 + static_cast<long>(k) * rows);
+				}
+				const double* __restrict__ bbase = T + n0 + static_cast<long>(k0) * ldt;
+#pragma unroll
+				for (int qq = 0; qq < NBv; ++qq)
+				{
+					const int i = t + NT * qq;
+					const int r2 = (i & 127) * 2, k = i >> 7;
+					breg[qq] = *reinterpret_cast<const d2*>(bbase + r2 + static_cast<long>(k) * ldt);
+				}
+			};
+			auto store_ab = [&](int buf) {
+				double* __restrict__ sa = As + buf * ASL;
+#pragma unroll
+				for (int qq = 0; qq < NA; ++qq)
+				{
+					const int i = t + NT * qq;
+					const int r2 = (i % (TM / 2)) * 2, k = i / (TM / 2);
+					*reinterpret_cast<d2*>(sa + k * ASr + r2) = areg[qq];
+				}
+				double* __restrict__ sb = Bs + buf * BSL;
+#pragma unroll
+				for (int qq = 0; qq < NBv; ++qq)
+				{
+					const int i = t + NT * qq;
+					const int r2 = (i & 127) * 2, k = i >> 7;
+					*reinterpret_cast<d2*>(sb + k * BS + r2) = breg[qq];
+				}
+			};
+			const int G = gridDim.y, g = blockIdx.y;
+			for (int jt = 0; jt < ntiles; ++jt)
+			{
+				const int pos = jt % (2 * G);
+				if ((pos < G ? pos : 2 * G - 1 - pos) != g) continue; // uniform; no accumulator is live here
+				const int n0 = jt * BN;
+				const int nk = (n0 + BN) / KB;
+				d4 acc[AF][BF];
+#pragma unroll
+				for (int i = 0; i < AF; ++i)
+#pragma unroll
+					for (int j = 0; j < BF; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+				__syncthreads();
+				load_ab(n0, 0);
+				store_ab(0);
+				__syncthreads();
+				// one k-step against the column blocks wn + WN t, t >= TMIN
+				auto kstep = [&](auto tmin_tag, int s) {
+					constexpr int TMIN = decltype(tmin_tag)::value;
+					if (s + 1 < nk) load_ab(n0, (s + 1) * KB);
+					const double* __restrict__ pa = As + (s & 1) * ASL + wm * (16 * AF) + fr;
+					const double* __restrict__ pb = Bs + (s & 1) * BSL + WNI * 16 + fr;
+#pragma unroll
+					for (int kk = 0; kk < KB; kk += 4)
+					{
+						double af[AF], bf[BF];
+#pragma unroll
+						for (int i = 0; i < AF; ++i) af[i] = pa[(kk + fk) * ASr + i * 16];
+#pragma unroll
+						for (int j = TMIN; j < BF; ++j) bf[j] = pb[(kk + fk) * BS + j * (16 * WN)];
+#pragma unroll
+						for (int i = 0; i < AF; ++i)
+#pragma unroll
+							for (int j = TMIN; j < BF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+					}
+					if (s + 1 < nk) store_ab((s + 1) & 1);
+					__syncthreads();
+				};
+				const int nd = n0 / KB;
+				for (int s = 0; s < nd; ++s) kstep(std::integral_constant<int, 0>{}, s);
+				// diagonal 256-block: step D starts at k = n0 + 16 D, the column blocks jb < D are zero; jb = WNI + WN t >= D  <=>  t >= ceil((D - WNI) / WN)
+				[&]<int... D>(std::integer_sequence<int, D...>) {
+					(kstep(std::integral_constant<int, (D > WNI ? (D - WNI + WN - 1) / WN : 0)>{}, nd + D), ...);
+				}(std::make_integer_sequence<int, BN / KB>{});
+#pragma unroll
+				for (int i = 0; i < AF; ++i)
+#pragma unroll
+					for (int j = 0; j < BF; ++j)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) rsq[i] = fma(acc[i][j][r], acc[i][j][r], rsq[i]);
+			}
+		}
+		template <int AF, int BF>
+		__global__ void __launch_bounds__(NTHREADS, 1) rownorm2_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt,
+			int n_total, double* __restrict__ q, long qstride)
+		{
+			constexpr int KB = 16, WN = 16 / BF, ASr = BM + 16;
+			__shared__ __attribute__((aligned(16))) double lds[2 * KB * ASr + 2 * KB * BS];
+			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int wm = w / WN, wn = w % WN;
+			const int m0 = blockIdx.x * BM;
+			double rsq[AF];
+#pragma unroll
+			for (int i = 0; i < AF; ++i) rsq[i] = 0.0;
+			// the tile loop once per column index of the wave (uniform branch, taken once; no accumulator is live across it)
+			if constexpr (WN == 4)
+			{
+				if (wn == 0) rownorm2_tiles<AF, BF, 0>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
+				else if (wn == 1) rownorm2_tiles<AF, BF, 1>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
+				else if (wn == 2) rownorm2_tiles<AF, BF, 2>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
+				else rownorm2_tiles<AF, BF, 3>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
+			}
+			else
+			{
+				if (wn == 0) rownorm2_tiles<AF, BF, 0>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
+				else rownorm2_tiles<AF, BF, 1>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
+			}
+			// rows of fragment i: m0 + wm * 16 AF + 16 i + (lane & 15); partial sums of the WN column groups meet in LDS
+			__syncthreads();
+#pragma unroll
+			for (int i = 0; i < AF; ++i)
+			{
+				double v = rsq[i];
+				v += __shfl_xor(v, 16);
+				v += __shfl_xor(v, 32);
+				if (lane < 16) lds[wn * BM + wm * (16 * AF) + 16 * i + lane] = v;
+			}
+			__syncthreads();
+			if (threadIdx.x < BM)
+			{
+				double v = 0.0;
+#pragma unroll
+				for (int c = 0; c < WN; ++c) v += lds[c * BM + threadIdx.x];
+				q[static_cast<long>(blockIdx.y) * qstride + m0 + threadIdx.x] = v;
+			}
+		}
+
+		// ---- two independent workgroups per CU -------------------------------------------------------------------------------
+		// In the kernels above the two waves that share a SIMD belong to the same workgroup: they meet the same barrier every
+		// k-step and wait for their LDS operands at the same moments, so neither covers the other's stalls (SQ_WAIT_ANY 15 % of
+		// the wave cycles ~ the idle share of the MFMA pipe).  Here a workgroup is 4 waves (one per SIMD) on a 128 x 128 tile,
+		// each wave 4 x 4 fragments (64 rows x 64 columns, 8 operand reads per 16 MFMAs); its 74 KB of LDS let TWO workgroups
+		// share a CU, and the two waves of a SIMD then come from different workgroups with unrelated barriers.  Price: K* is
+		// re-read once per 128-column tile of T instead of per 256 (twice the HBM stream, still far below the roofline).
+		constexpr int BN3 = 128, BS3 = BN3 + 16, NT3 = 256;
+		template <int WNI>
+		__device__ __forceinline__ void rownorm3_tiles(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt, int n_total,
+			double* lds, double (&rsq)[4], int m0, int wm)
+		{
+			constexpr int KB = 16, AF = 4, BF = 4, WN = 2;
+			constexpr int ASr = BM + 16;
+			constexpr int ASL = KB * ASr, BSL = KB * BS3;
+			constexpr int NA = BM * KB / 2 / NT3, NBv = BN3 * KB / 2 / NT3; // 4 + 4 double2 per thread and slab
+			double* const As = lds;
+			double* const Bs = lds + 2 * ASL;
+			const int t = threadIdx.x, lane = t & 63;
+			const int fk = lane >> 4, fr = lane & 15;
+			const int ntiles = n_total / BN3;
+			d2 areg[NA], breg[NBv];
+			auto load_ab = [&](int n0, int k0) {
+				const double* __restrict__ abase = Ks + m0 + static_cast<long>(k0) * rows;
+				const double* __restrict__ bbase = T + n0 + static_cast<long>(k0) * ldt;
+#pragma unroll
+				for (int qq = 0; qq < NA; ++qq)
+				{
+					const int i = t + NT3 * qq;
+					const int r2 = (i & 63) * 2, k = i >> 6;
+					areg[qq] = *reinterpret_cast<const d2*>(abase + r2 + static_cast<long>(k) * rows);
+					breg[qq] = *reinterpret_cast<const d2*>(bbase + r2 + static_cast<long>(k) * ldt);
+				}
+			};
+			auto store_ab = [&](int buf) {
+				double* __restrict__ sa = As + buf * ASL;
+				double* __restrict__ sb = Bs + buf * BSL;
+#pragma unroll
+				for (int qq = 0; qq < NA; ++qq)
+				{
+					const int i = t + NT3 * qq;
+					const int r2 = (i & 63) * 2, k = i >> 6;
+					*reinterpret_cast<d2*>(sa + k * ASr + r2) = areg[qq];
+					*reinterpret_cast<d2*>(sb + k * BS3 + r2) = breg[qq];
+				}
+			};
+			const int G = gridDim.y, g = blockIdx.y;
+			for (int jt = 0; jt < ntiles; ++jt)
+			{
+				const int pos = jt % (2 * G);
+				if ((pos < G ? pos : 2 * G - 1 - pos) != g) continue;
+				const int n0 = jt * BN3;
+				const int nk = (n0 + BN3) / KB;
+				d4 acc[AF][BF];
+#pragma unroll
+				for (int i = 0; i < AF; ++i)
+#pragma unroll
+					for (int j = 0; j < BF; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+				__syncthreads();
+				load_ab(n0, 0);
+				store_ab(0);
+				__syncthreads();
+				auto kstep = [&](auto tmin_tag, int s) {
+					constexpr int TMIN = decltype(tmin_tag)::value;
+					if (s + 1 < nk) load_ab(n0, (s + 1) * KB);
+					const double* __restrict__ pa = As + (s & 1) * ASL + wm * 64 + fr;
+					const double* __restrict__ pb = Bs + (s & 1) * BSL + WNI * 16 + fr;
+#pragma unroll
+					for (int kk = 0; kk < KB; kk += 4)
+					{
+						double af[AF], bf[BF];
+#pragma unroll
+						for (int i = 0; i < AF; ++i) af[i] = pa[(kk + fk) * ASr + i * 16];
+#pragma unroll
+						for (int j = TMIN; j < BF; ++j) bf[j] = pb[(kk + fk) * BS3 + j * (16 * WN)];
+#pragma unroll
+						for (int i = 0; i < AF; ++i)
+#pragma unroll
+							for (int j = TMIN; j < BF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+					}
+					if (s + 1 < nk) store_ab((s + 1) & 1);
+					__syncthreads();
+				};
+				const int nd = n0 / KB;
+				for (int s = 0; s < nd; ++s) kstep(std::integral_constant<int, 0>{}, s);
+				// diagonal 128-block: 8 k-steps, column block jb = WNI + 2 t is zero for jb < D
+				[&]<int... D>(std::integer_sequence<int, D...>) {
+					(kstep(std::integral_constant<int, (D > WNI ? (D - WNI + WN - 1) / WN : 0)>{}, nd + D), ...);
+				}(std::make_integer_sequence<int, BN3 / KB>{});
+#pragma unroll
+				for (int i = 0; i < AF; ++i)
+#pragma unroll
+					for (int j = 0; j < BF; ++j)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) rsq[i] = fma(acc[i][j][r], acc[i][j][r], rsq[i]);
+			}
+		}
+		__global__ void __launch_bounds__(NT3, 2) rownorm3_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt,
+			int n_total, double* __restrict__ q, long qstride)
+		{
+			constexpr int KB = 16, ASr = BM + 16;
+			__shared__ __attribute__((aligned(16))) double lds[2 * KB * ASr + 2 * KB * BS3];
+			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int wm = w >> 1, wn = w & 1;
+			const int m0 = blockIdx.x * BM;
+			double rsq[4] = {0.0, 0.0, 0.0, 0.0};
+			if (wn == 0) rownorm3_tiles<0>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
+			else rownorm3_tiles<1>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
+			__syncthreads();
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+			{
+				double v = rsq[i];
+				v += __shfl_xor(v, 16);
+				v += __shfl_xor(v, 32);
+				if (lane < 16) lds[wn * BM + wm * 64 + 16 * i + lane] = v;
+			}
+			__syncthreads();
+			if (threadIdx.x < BM) q[static_cast<long>(blockIdx.y) * qstride + m0 + threadIdx.x] = lds[threadIdx.x] + lds[BM + threadIdx.x];
+		}
+
 		// plane blockIdx.y of the partial sums -> out[plane][row]
 		__global__ void __launch_bounds__(256) sum_mu_kernel(const double* __restrict__ mu_part, int m_rows, int ksplit, double* __restrict__ out)
 		{
@@ -353,10 +630,14 @@ namespace gple
 		if (a.M <= 0) return hipSuccess;
 		if (a.m_rows % BM || a.n_total % BN || a.m_split % BM || a.n_split % BN || chunk_rows % BM || chunk_rows <= 0)
 			return hipErrorInvalidValue;
-		static const int variant = [] {
+		// 0: 8 waves x (16 rows x 256 columns); 1: 4 waves, BK 8, two workgroups per CU; 2 / 3: 8 waves x (4 x 4) / (2 x 8) fragments;
+		// 4: 4 waves x (4 x 4) on a 128 x 128 tile, two workgroups per CU.  Measured at C2 / C4r (TFLOP/s, same box): 60.1 / 65.07,
+		// — / 61 (round 1), 59.6 / 65.78, 60.4 / 65.75, 60.0 / 64.02.  Default: 2 from eight N-tiles on (+1.1 % at C4r), else 0.
+		static const int forced = [] {
 			const char* e = getenv("GPLE_ROWNORM_VARIANT");
-			return e ? atoi(e) : 0;
+			return e ? atoi(e) : -1;
 		}();
+		const int variant = forced >= 0 ? forced : (a.n_total / BN >= 8 ? 2 : 0);
 		double* Ks = scratch;
 		double* mu_part = scratch + static_cast<size_t>(chunk_rows) * a.n_total;
 		const bool small = few_rows && chunk_rows == a.m_rows;
@@ -384,6 +665,21 @@ namespace gple
 				hipLaunchKernelGGL(colsumsq_kernel, dim3(rows), dim3(256), 0, s, Z, static_cast<long>(a.n_total), a.n_total, a.q + row0);
 			}
 			else if (variant == 1) hipLaunchKernelGGL((rownorm_kernel<4, 8>), dim3(rows / 64), dim3(256), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0, 0L);
+			else if (variant == 4)
+			{
+				const int G = split;
+				double* qdst = G > 1 ? qpart + row0 : a.q + row0;
+				hipLaunchKernelGGL(rownorm3_kernel, dim3(rows / BM, G), dim3(NT3), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows));
+			}
+			else if (variant == 2 || variant == 3)
+			{
+				const int G = split;
+				double* qdst = G > 1 ? qpart + row0 : a.q + row0;
+				if (variant == 2)
+					hipLaunchKernelGGL((rownorm2_kernel<4, 4>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows));
+				else
+					hipLaunchKernelGGL((rownorm2_kernel<2, 8>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows));
+			}
 			else
 			{
 				// fewer than two workgroups per CU: split the N-tiles of every row block over G workgroups (partial sums)
