@@ -162,6 +162,10 @@ namespace
 	constexpr int SDEV_N = 512;        // [0] s, [1..15] base sums, [16..28] real derivative sums, [31] info, [32..39] complex error derivative,
 	                                   // [64..108] complex purity quadratic forms (5 kernels x 9), [128..287] aux dots (5 x 8 x 4)
 	constexpr int HS_PRED_ERR = 512, HS_PRED_DERIV = 520, HS_NLML = 540;
+	// a handful of test points with host pointers (the reference's one-point predicts): inputs and outputs go through the pinned
+	// block itself (device-visible), not through four hipMemcpyAsync of pageable memory
+	constexpr int HS_FEW_XS = 600, HS_FEW_LAB = 640, HS_FEW_MEAN = 680, HS_FEW_VAR = 720, HS_FEW_CUT = 740;
+	constexpr size_t FEW_HOST_POINTS = 16;
 
 	// pooled buffer with scope lifetime
 	struct Scratch
@@ -1063,7 +1067,13 @@ extern "C"
 		Scratch xs(ctx), q(ctx), mu(ctx), lab(ctx), o_mean(ctx), o_var(ctx), o_cut(ctx), epart(ctx), dacc(ctx), dpart(ctx);
 		timer_start(ctx, GPLE_TIMER_PREDICT);
 		const double* xs_dev = Xs;
-		if (!dev)
+		const bool small_host = !dev && M <= FEW_HOST_POINTS && !(flags & PREDICT_NO_SYNC); // (a deferred call must not leave its inputs in the shared block)
+		if (small_host)
+		{
+			std::memcpy(ctx->host_scalars + HS_FEW_XS, Xs, 2 * M * sizeof(double));
+			xs_dev = ctx->host_scalars + HS_FEW_XS;
+		}
+		else if (!dev)
 		{
 			GPLE_HIP(ctx, xs.get(2 * M));
 			GPLE_HIP(ctx, copy_in(st, xs.p, Xs, 2 * M, false));
@@ -1085,17 +1095,36 @@ extern "C"
 		int chunk_rows = 0;
 		bool few_rows = false;
 		Scratch kstar(ctx);
-		GPLE_HIP(ctx, kstar.get(predict_scratch_doubles(a, &chunk_rows, &few_rows)));
-		GPLE_HIP(ctx, launch_predict_q(ctx, st, a, kstar.p, chunk_rows, few_rows));
+		if (predict_is_few(a)) // one-point predicts of the reference's callers: no padding, no K*, no GEMM
+		{
+			GPLE_HIP(ctx, kstar.get(predict_few_scratch_doubles(a)));
+			GPLE_HIP(ctx, launch_predict_few(st, a, kstar.p));
+		}
+		else
+		{
+			GPLE_HIP(ctx, kstar.get(predict_scratch_doubles(a, &chunk_rows, &few_rows)));
+			GPLE_HIP(ctx, launch_predict_q(ctx, st, a, kstar.p, chunk_rows, few_rows));
+		}
 		const double* lab_dev = labels;
-		if (labels && !dev)
+		if (labels && small_host)
+		{
+			std::memcpy(ctx->host_scalars + HS_FEW_LAB, labels, ow * M * sizeof(double));
+			lab_dev = ctx->host_scalars + HS_FEW_LAB;
+		}
+		else if (labels && !dev)
 		{
 			GPLE_HIP(ctx, lab.get(ow * M));
 			GPLE_HIP(ctx, copy_in(st, lab.p, labels, ow * M, false));
 			lab_dev = lab.p;
 		}
 		double *d_mean = prediction, *d_var = variance, *d_cut = cutoff_prediction;
-		if (!dev)
+		if (small_host)
+		{
+			if (prediction) d_mean = ctx->host_scalars + HS_FEW_MEAN;
+			if (variance) d_var = ctx->host_scalars + HS_FEW_VAR;
+			if (cutoff_prediction) d_cut = ctx->host_scalars + HS_FEW_CUT;
+		}
+		else if (!dev)
 		{
 			if (prediction)
 			{
@@ -1139,7 +1168,7 @@ extern "C"
 				GPLE_HIP(ctx, launch_predict_deriv_finish_real(st, dacc.p, m_rows, q.p, Mi, f->self, f->sf, f->sdev, lab_dev, dpart.p, dpart.p + 8 * nblk));
 			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_PRED_DERIV, dpart.p + 8 * nblk, 8 * 8, hipMemcpyDeviceToHost, st));
 		}
-		if (!dev)
+		if (!dev && !small_host)
 		{
 			GPLE_HIP(ctx, copy_out(st, prediction, d_mean, ow * M, false));
 			GPLE_HIP(ctx, copy_out(st, variance, d_var, M, false));
@@ -1153,6 +1182,12 @@ extern "C"
 		{
 			GPLE_HIP(ctx, hipStreamSynchronize(st));
 			timer_collect(ctx);
+		}
+		if (small_host) // the kernels wrote into the pinned block
+		{
+			if (prediction) std::memcpy(prediction, ctx->host_scalars + HS_FEW_MEAN, ow * M * sizeof(double));
+			if (variance) std::memcpy(variance, ctx->host_scalars + HS_FEW_VAR, M * sizeof(double));
+			if (cutoff_prediction) std::memcpy(cutoff_prediction, ctx->host_scalars + HS_FEW_CUT, ow * M * sizeof(double));
 		}
 		predict_scalars_from_host(ctx, labels != nullptr, want_deriv, cplx, scalars);
 		return GPLE_OK;

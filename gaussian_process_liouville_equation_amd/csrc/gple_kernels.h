@@ -125,6 +125,7 @@ namespace gple
 		int M;            // number of test points
 		int m_rows;       // rows of the (typed) test set: Mh (real) or 2*Mh (complex), Mh = round_up(M, 128)
 		int m_split;      // rows >= m_split are imaginary-part rows (== m_rows for the real GP)
+		int m_split_few;  // few-points path only: the same boundary in its compact row numbering
 		const double* Xt; // training points (N valid, readable up to n_split entries)
 		int N;
 		int n_total; // Np or 2*Np
@@ -146,6 +147,10 @@ namespace gple
 	constexpr size_t PREDICT_SCRATCH_BYTES = size_t(4) << 30;
 	// doubles of scratch launch_predict_q needs for `a`; *chunk_rows = rows of the typed test set handled per pass
 	size_t predict_scratch_doubles(const PredictArgs& a, int* chunk_rows, bool* few_rows);
+	// a handful of test points (<= 16 typed rows, no derivatives): triangular mat-vecs with K* generated on the fly
+	bool predict_is_few(const PredictArgs& a);
+	size_t predict_few_scratch_doubles(const PredictArgs& a);
+	hipError_t launch_predict_few(hipStream_t s, const PredictArgs& a, double* scratch);
 	// fills a.q and a.mu; per chunk: kstar_gen_kernel then rownorm_kernel (bracketed by the context's chunk timers)
 	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows, bool few_rows);
 	// real finish: var = self - q, cutoff, cut = mu*cf/s ; optional labels -> err_out[0] += sum (mu - s t)^2

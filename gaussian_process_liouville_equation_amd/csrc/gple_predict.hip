@@ -553,6 +553,144 @@ namespace gple
 			if (threadIdx.x < BM) q[static_cast<long>(blockIdx.y) * qstride + m0 + threadIdx.x] = lds[threadIdx.x] + lds[BM + threadIdx.x];
 		}
 
+		// ---- a handful of test points (the one-point predicts of main.cpp:75-101, evolve.cpp:298, mc.cpp:158-172) --------------
+		// For M <= FEW_MAX typed rows the tiled paths pad to 128 rows, materialise K* and run a GEMM against all of T: 0.1-0.65 ms
+		// per call, almost all of it launches, padding and copies.  Here the contraction is a triangular mat-vec per point with K*
+		// generated on the fly: workgroup (bx, by) owns 64 rows of T and every KS-th 64-wide chunk of k up to its last row; k*(k)
+		// of every point is computed once per workgroup and chunk into LDS (one exp per thread and point), each thread streams
+		// two rows x 8 k of T per chunk (double2 loads, all eight in flight) and the partial products u = T k* go to a small
+		// buffer; a second kernel adds the KS partial vectors, squares and sums them.  T is read once (lower triangle).
+		constexpr int FEW_MAX = 16, FEW_ROWS = 64, FEW_KC = 64, FEW_KS_MAX = 8;
+		__global__ void __launch_bounds__(256) predict_few_kernel(const PredictArgs a, int mt, double* __restrict__ upart, double* __restrict__ mupart)
+		{
+			__shared__ double ks[FEW_MAX][FEW_KC];
+			__shared__ double red[4][FEW_MAX][FEW_ROWS];
+			const int t = threadIdx.x, li = t & 31, sl = t >> 5; // row pair inside the block, k-slice
+			const int i0 = blockIdx.x * FEW_ROWS;
+			const int nchunks = blockIdx.x + 1; // T(i, k) = 0 for k > i
+			const int KS = gridDim.y, by = blockIdx.y;
+			const bool last = blockIdx.x == gridDim.x - 1;
+			double u0[FEW_MAX], u1[FEW_MAX], mu[FEW_MAX];
+#pragma unroll
+			for (int m = 0; m < FEW_MAX; ++m) u0[m] = 0.0, u1[m] = 0.0, mu[m] = 0.0;
+			for (int c = by; c < nchunks; c += KS)
+			{
+				const int kc = c * FEW_KC;
+				// the eight double2 of this thread for the chunk: requested before the k* generation, consumed after it
+				d2 tv[8];
+				const double* __restrict__ tb = a.T + (i0 + 2 * li) + static_cast<long>(kc + sl) * a.ldt;
+#pragma unroll
+				for (int j = 0; j < 8; ++j) tv[j] = *reinterpret_cast<const d2*>(tb + static_cast<long>(8 * j) * a.ldt);
+				__syncthreads();
+				{
+					const int k = kc + (t & 63);
+					const int type_k = k >= a.n_split;
+					const int pk = type_k ? k - a.n_split : k;
+					const bool valid = pk < a.N;
+					const int pc = valid ? pk : 0;
+					const double xk = a.Xt[2 * pc], pkv = a.Xt[2 * pc + 1];
+					for (int m = t >> 6; m < mt; m += 4)
+					{
+						const int type_m = m >= a.m_split_few;
+						const int pidx = type_m ? m - a.m_split_few : m;
+						const SEParam& p = a.ps.p[type_m + type_k];
+						const double xm = a.Xs[2 * pidx], pm = a.Xs[2 * pidx + 1];
+						const double d0 = (xm - xk) * p.rl0, d1 = (pm - pkv) * p.rl1;
+						const double g = exp_nonpos(-0.5 * (d0 * d0 + d1 * d1));
+						const double delta = (type_m == type_k && xm == xk && pm == pkv) ? p.n2 : 0.0;
+						ks[m][t & 63] = valid ? p.amp * (g + delta) : 0.0;
+					}
+				}
+				__syncthreads();
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+				{
+					const int kk = sl + 8 * j;
+#pragma unroll
+					for (int m = 0; m < FEW_MAX; ++m)
+						if (m < mt)
+						{
+							const double kv = ks[m][kk];
+							u0[m] = fma(tv[j].x, kv, u0[m]);
+							u1[m] = fma(tv[j].y, kv, u1[m]);
+						}
+				}
+				if (last && t < FEW_KC) // the last row block sees every k: it also reduces the mean k* . v
+				{
+					const double vk = a.v[kc + t];
+#pragma unroll
+					for (int m = 0; m < FEW_MAX; ++m)
+						if (m < mt) mu[m] = fma(ks[m][t], vk, mu[m]);
+				}
+			}
+			// sum over the 8 k-slices: the upper four hand theirs to the lower four through LDS, the lower four publish the sums
+			__syncthreads();
+			if (sl >= 4)
+			{
+#pragma unroll
+				for (int m = 0; m < FEW_MAX; ++m)
+					if (m < mt) red[sl - 4][m][2 * li] = u0[m], red[sl - 4][m][2 * li + 1] = u1[m];
+			}
+			__syncthreads();
+			if (sl < 4)
+			{
+#pragma unroll
+				for (int m = 0; m < FEW_MAX; ++m)
+					if (m < mt) u0[m] += red[sl][m][2 * li], u1[m] += red[sl][m][2 * li + 1];
+			}
+			__syncthreads();
+			if (sl < 4)
+			{
+#pragma unroll
+				for (int m = 0; m < FEW_MAX; ++m)
+					if (m < mt) red[sl][m][2 * li] = u0[m], red[sl][m][2 * li + 1] = u1[m];
+			}
+			__syncthreads();
+			for (int idx = t; idx < mt * FEW_ROWS; idx += 256)
+			{
+				const int m = idx >> 6, r = idx & 63;
+				upart[(static_cast<long>(by) * FEW_MAX + m) * a.n_total + i0 + r] = (red[0][m][r] + red[1][m][r]) + (red[2][m][r] + red[3][m][r]);
+			}
+			if (last && t < FEW_KC)
+			{
+#pragma unroll
+				for (int m = 0; m < FEW_MAX; ++m)
+					if (m < mt)
+					{
+						double s = mu[m];
+#pragma unroll
+						for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+						if (t == 0) mupart[by * FEW_MAX + m] = s;
+					}
+			}
+		}
+		// q[row(m)] = sum_i (sum_by upart)^2, mu[row(m)] = sum_by mupart; row(m): compact typed row -> padded layout; one workgroup per m
+		__global__ void __launch_bounds__(256) predict_few_reduce_kernel(const double* __restrict__ upart, const double* __restrict__ mupart, int KS, int n_total,
+			int m_split_few, int m_split, double* __restrict__ q, double* __restrict__ mu)
+		{
+			__shared__ double red[4];
+			const int m = blockIdx.x;
+			double s = 0.0;
+			for (int i = threadIdx.x; i < n_total; i += 256)
+			{
+				double u = 0.0;
+				for (int b = 0; b < KS; ++b) u += upart[(static_cast<long>(b) * FEW_MAX + m) * n_total + i];
+				s = fma(u, u, s);
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+			if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+			__syncthreads();
+			if (threadIdx.x == 0)
+			{
+				const int row = m >= m_split_few ? m_split + (m - m_split_few) : m;
+				q[row] = (red[0] + red[1]) + (red[2] + red[3]);
+				double ms = 0.0;
+				for (int b = 0; b < KS; ++b) ms += mupart[b * FEW_MAX + m];
+				mu[row] = ms;
+			}
+		}
+
 		// plane blockIdx.y of the partial sums -> out[plane][row]
 		__global__ void __launch_bounds__(256) sum_mu_kernel(const double* __restrict__ mu_part, int m_rows, int ksplit, double* __restrict__ out)
 		{
@@ -623,6 +761,40 @@ namespace gple
 		*chunk_rows = static_cast<int>(rows);
 		return rows * a.n_total + static_cast<size_t>(gen_ksplit(a.m_rows)) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1)
 			+ (small ? rows * a.n_total : 0) + static_cast<size_t>(ROWNORM_SPLIT_MAX) * a.m_rows;
+	}
+
+	bool predict_is_few(const PredictArgs& a)
+	{
+		static const bool off = [] {
+			const char* e = getenv("GPLE_PREDICT_FEW");
+			return e && e[0] == '0';
+		}();
+		const int mt = (a.m_split < a.m_rows ? 2 : 1) * a.M; // typed rows
+		return !off && a.dv == nullptr && mt <= FEW_MAX;
+	}
+	static int predict_few_ksplit(int n_total)
+	{
+		const int nblk = n_total / FEW_ROWS;
+		int ks = (256 + nblk - 1) / nblk; // about one workgroup per CU
+		return ks < 1 ? 1 : (ks > FEW_KS_MAX ? FEW_KS_MAX : ks);
+	}
+	size_t predict_few_scratch_doubles(const PredictArgs& a)
+	{
+		return static_cast<size_t>(FEW_KS_MAX) * FEW_MAX * (static_cast<size_t>(a.n_total) + 1);
+	}
+	hipError_t launch_predict_few(hipStream_t s, const PredictArgs& a0, double* scratch)
+	{
+		PredictArgs a = a0;
+		const bool cplx = a.m_split < a.m_rows;
+		const int mt = (cplx ? 2 : 1) * a.M;
+		a.m_split_few = cplx ? a.M : mt;
+		const int nblk = a.n_total / FEW_ROWS, KS = predict_few_ksplit(a.n_total);
+		double* upart = scratch;
+		double* mupart = scratch + static_cast<size_t>(FEW_KS_MAX) * FEW_MAX * a.n_total;
+		// a k-slice that owns no chunk of a row block (by >= chunks of the block) still writes its zeros: no stale partials
+		hipLaunchKernelGGL(predict_few_kernel, dim3(nblk, KS), dim3(256), 0, s, a, mt, upart, mupart);
+		hipLaunchKernelGGL(predict_few_reduce_kernel, dim3(mt), dim3(256), 0, s, upart, mupart, KS, a.n_total, a.m_split_few, a.m_split, a.q, a.mu);
+		return hipGetLastError();
 	}
 
 	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows, bool few_rows)

@@ -411,3 +411,29 @@ def test_resident_objective_equals_loose_function(gpu):
     empty = gpu.objective(X, y.astype(complex), np.zeros((0, 2)), np.zeros(0, complex))  # no extra set
     v, _ = empty([1.0, 0.7086, 0.7056, 1e-2], want_grad=False)
     assert v == gpu.loose_function([1.0, 0.7086, 0.7056, 1e-2], X, y.astype(complex), np.zeros((0, 2)), np.zeros(0, complex), want_grad=False)[0]
+
+
+def test_few_points_predict_path(gpu, oracle, monkeypatch):
+    """<= 16 typed rows take the one-point path (triangular mat-vec with K* generated on the fly): against the tiled path on the
+    same points and against the oracle, real and complex, 1 .. 16 points, incl. a training point (delta kernel) and N not a
+    multiple of the row block"""
+    X, yr, Xs = parity.synthetic_real(333, 16, 404)
+    Xs[3] = X[17]
+    yc = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0))
+    th, thc = [1.0, 0.7086, 0.7056, 1e-2], [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05]
+    fr, fc = gpu.real_fit(th, X, yr, 0), gpu.complex_fit(thc, X, yc, 0)
+    fro, fco = oracle.real_fit(th, X, yr, 0), oracle.complex_fit(thc, X, yc, 0)
+    for m in (1, 2, 5, 8, 16):
+        for fit, fo, pred, po, lim in ((fr, fro, gpu.real_predict, oracle.real_predict, 16), (fc, fco, gpu.complex_predict, oracle.complex_predict, 8)):
+            monkeypatch.setenv("GPLE_PREDICT_FEW", "1")
+            few = pred(fit, Xs[:m])
+            ref = po(fo, Xs[:m])
+            scale = np.abs(ref["prediction"]).max()
+            assert np.abs(few["prediction"] - ref["prediction"]).max() <= 1e-9 * scale
+            assert np.abs(few["variance"] - ref["variance"]).max() <= 1e-8
+            assert np.abs(few["cutoff"] - ref["cutoff"]).max() <= 1e-8 * scale / fo.scalars["rescale_factor"]
+    # labels still work on few points (error through the same finish kernel)
+    lab = yr[:4]
+    e_few = gpu.real_predict(fr, X[:4], labels=lab)["error"]
+    e_ref = oracle.real_predict(fro, X[:4], labels=lab)["error"]
+    assert abs(e_few - e_ref) <= 1e-7 * max(abs(e_ref), 1e-12) + 1e-12
