@@ -33,6 +33,8 @@ WORKLOADS = {  # name: (N, G, kernel)
     "C4c": (4096, 512, "complex"),  # the complex element of C4
     "C5r": (8192, 1024, "real"),    # one real element of C5
     "C4opt": (4096, 0, "opt"),      # the opt.cpp loop of configs[3]: 2 real + 1 complex objective evaluations with gradient
+    "C2step": (1024, 0, "step"),    # one tick of main.cpp:143-176 at N = 1024: evolve density + 5N extra points, refit 3 elements
+    "C5step": (8192, 0, "step"),    # the same at the N of configs[4] (two-level physics: what the reference instantiates)
 }
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak; measured 78.4 with v_mfma_f64_16x16x4_f64
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
@@ -176,6 +178,8 @@ def main():
             dist.init_process_group("gloo")
     if args.workload == "C4opt":
         return opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev)
+    if WORKLOADS[args.workload][2] == "step":
+        return step_loop(args, pkg, torch, dist, rank, world, dev)
 
     N, G, kernel = WORKLOADS[args.workload]
     cplx = kernel == "complex"
@@ -293,7 +297,7 @@ def main():
         "config": {"workload": f"{args.workload}: N={N} samples, {G}x{G} grid (M={M}), {kernel} SE kernel, fit(error+average) + grid predict(mean,var,cutoff)",
                    "N": N, "M": M, "parallelism": (f"{world} independent density-matrix elements, one per GPU, no data-path collective" if by_element else
                                    f"grid-sharded x{world}, replicated fit, {'RCCL' if args.backend == 'nccl' else 'gloo (host)'} all-gather") if world > 1 else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": "rownorm_kernel (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
+        "roofline": {"bound": "mfma", "kernel": ("rownorm2_kernel<4,4>" if nn >= 2048 else "rownorm_kernel<8,16>") + " (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
                      "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(pk_ms, 4), "launches_per_step": launches_per_step,
                      "algorithmic_flops_per_launch": flops,
@@ -314,6 +318,72 @@ def main():
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(args.workload, N, G, kernel, X, y, grid, theta)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    api.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def step_loop(args, pkg, torch, dist, rank, world, dev):
+    """--workload C2step / C5step: one tick of the reference's main loop (main.cpp:143-176) per step, all on the device:
+    evolve(density) + evolve(extra points, 5N per element) — 8 back-propagated points per sample, predicted in three batches —
+    then TrainingKernels(params, density) (three fits with error + averages).  Single GPU (replicas with --gpus N)."""
+    from gaussian_process_liouville_equation_amd import kernels as K, steploop
+    N = WORKLOADS[args.workload][0]
+    order = [(0, 0), (1, 0), (1, 1)]
+    dens, extra, params = {}, {}, {}
+    for k, e in enumerate(order):
+        cplx = e[0] != e[1]
+        X, y, _, theta = synthetic(N, 1, 20240607 + 50 + k + 10 * rank, "complex" if cplx else "real")
+        X[:, 0] += 8.5  # the packet about to enter the coupling region of Tully's second model
+        Xe, ye = extra_points(X, 20240607 + 60 + k, "complex" if cplx else "real")
+        scale = (0.6, 1.0, 0.4)[k]
+        dens[e] = (X, np.asarray(y, dtype=complex) * scale)
+        extra[e] = (Xe, ye * scale)
+        params[e] = list(theta)
+    api = pkg.open_api(dev)
+    kernels = K.TrainingKernels(params, K.construct_training_sets(dens, 2), True, True, False, api=api, num_pes=2)
+    state = {"d": dens, "x": extra, "k": kernels}
+
+    def step():
+        state["d"], state["x"], state["k"] = steploop.tick(state["d"], state["x"], params, 2000.0, 1.0, state["k"], steploop.DAC, api)
+        return state["k"].calculate_population()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pop = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not np.isfinite(pop):
+        raise RuntimeError("non-finite population after the tick")
+    ms = 1e3 * elapsed / args.steps
+    # contraction flops of the three batched predicts of one evolve: 8 (N + 5N) points per element; complex: 2 typed rows, n = 2N
+    rows = 8 * 6 * N
+    F = 2 * float(rows) * N * (N + 1) + float(2 * rows) * (2 * N) * (2 * N + 1)
+    result = {
+        "metric": "GP fit+predict ms/step (N samples, M grid pts)", "value": round(ms, 3), "unit": "ms/step", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: one tick of main.cpp:143-176, N={N} points per element, 3 elements (2 real + 1 complex), 5N extra points each, "
+                               f"Tully II, {8 * 6 * N} back-propagated points per element and tick in one batch", "N": N, "M": 8 * 6 * N,
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
+        "roofline": {"bound": "mfma", "kernel": "rownorm kernels of the three batched predicts", "achieved": round(F / (ms * 1e-3) / 1e12, 3), "peak": FP64_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(F / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                     "note": "whole-tick rate: contraction flops of the predicts / tick time (fits, K* generation and the host round trips of the Python mirror included)"},
+        "population_after": pop,
+    }
     if rank == 0:
         print(json.dumps(result), flush=True)
     api.close()

@@ -99,3 +99,35 @@ def test_metropolis_chains_against_oracle(gpu, oracle):
     # no steps: nothing moves
     r0, a0 = gpu.markov_chain(fg, 0, 0.3, 1, start)
     assert np.array_equal(r0, start) and np.all(a0 == 0)
+
+
+def test_tick_mirror_and_phase_files(gpu, oracle):
+    """steploop.tick (main.cpp:143-176: evolve density and extra points, refit) keeps the packet's population, and the phase /
+    variance files written from the new kernels (output.cpp:180-232, row N4) match the oracle's line by line"""
+    import io
+    from gaussian_process_liouville_equation_amd import output, steploop
+    dens = _case(120, 77)
+    extra = _case(200, 78)
+    params = {(0, 0): TH, (1, 0): THC, (1, 1): TH}
+    k0 = K.TrainingKernels(params, K.construct_training_sets(dens), True, True, False, api=gpu)
+    pop0 = k0.calculate_population()
+    d1, x1, k1 = steploop.tick(dens, extra, params, MASS, DT, k0, steploop.DAC)
+    assert all(len(d1[e][0]) == len(dens[e][0]) and len(x1[e][0]) == len(extra[e][0]) for e in dens)
+    assert abs(k1.calculate_population() - pop0) <= 0.05 * abs(pop0)  # one tick of unitary dynamics on a fitted density
+    # the same tick on the oracle side, then both sets of files
+    fo = _fits(oracle, dens)
+    ref = E.evolve(dens, MASS, DT, _oracle_distribution(oracle, fo), E.DAC)
+    ko = K.TrainingKernels(params, K.construct_training_sets(ref), True, True, False, api=oracle)
+    grid = np.stack(np.meshgrid(np.linspace(-3.5, 0.5, 9), np.linspace(12.5, 15.5, 7), indexing="ij"), axis=-1).reshape(-1, 2)
+    files = {}
+    for name, ks in (("gpu", k1), ("oracle", ko)):
+        ph, va = io.StringIO(), io.StringIO()
+        output.output_phase(ph, va, ks, grid)
+        files[name] = (ph.getvalue(), va.getvalue())
+    for a, b in zip(files["gpu"], files["oracle"]):
+        la, lb = a.split("\\n"), b.split("\\n")
+        assert len(la) == len(lb)
+        for x, y in zip(la, lb):
+            assert len(x.split()) == len(y.split())
+            if x.strip():
+                assert np.allclose(np.array(x.split(), float), np.array(y.split(), float), rtol=2e-4, atol=1e-7)  # %g keeps 6 digits
