@@ -146,3 +146,35 @@ def test_predict_batch_against_pointwise_and_oracle(gpu, oracle):
             one = 0.0
         assert abs(out[i] - one) <= 1e-12 * scale
     assert gpu.predict_batch([fr, fc, None], np.zeros((0, 2)), np.zeros(0, np.int32)).size == 0
+
+
+@pytest.mark.parametrize("coherence", [0, 1])
+def test_optimization_adapter_runs_the_reference_tiers(gpu, coherence):
+    """host/opt.h (N2, C++ side): Optimization(InitParams, E, purity).optimize(density, extra) as main.cpp:71-74 calls it, on the
+    initial Gaussian (all population on surface 0) and on a three-element density.  The searches are the library's own, so the
+    iterates are not the reference's; what is checked is what opt.cpp guarantees whatever the search: parameters inside the
+    bounds of opt.cpp:1027-1047, 3 + 2 step counters (opt.cpp:1154-1176), a tier of opt.h:20-30, the averages of the returned
+    parameters inside AverageTolerance when the tier is LocalPrevious (opt.cpp:1320-1326), and a finite error that the second
+    call (which starts from the first call's parameters) does not make worse by more than the search tolerance."""
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_opt")
+    if not os.path.exists(exe):
+        pytest.fail("tests/cpp/dropin_opt missing: run __graft_entry__.build()")
+    out = subprocess.run([exe, "120", str(coherence)], check=True, capture_output=True, text=True, timeout=600).stdout
+    got, rows = {}, []
+    for line in out.strip().splitlines():
+        if line.startswith(" "):
+            rows.append([float(v) for v in line.split()])
+            continue
+        key, *vals = line.split()
+        got[key] = np.array([float(v) for v in vals])
+    assert np.isfinite(got["opt_error"][0]) and got["opt_error"][0] >= 0
+    assert got["opt_type"][0] in (1, 2, 3) and len(got["opt_steps"]) == 3 + 2 and got["opt_steps"][0] > 0
+    assert got["inside_bounds"][0] == 1
+    assert [len(r) for r in rows] == [4, 4, 4, 8, 8, 8, 4, 4, 4]  # output.cpp:120-132: lb / param / ub per element
+    lb, pr, ub = np.array(rows[0]), np.array(rows[1]), np.array(rows[2])
+    assert np.all(lb[1:] <= pr[1:]) and np.all(pr[1:] <= ub[1:]) and lb[3] == ub[3] == 1e-2  # only the lengths move (opt.cpp:33-61)
+    if got["opt_type"][0] == 1:  # LocalPrevious is only returned when check_averages was all inside the tolerance
+        assert abs(got["population"][0] - 1.0) < 0.05
+        assert abs(got["energy"][0] / got["energy"][1] - 1.0) < 0.05
+        assert abs(got["purity"][0] / got["purity"][1] - 1.0) < 0.05
+    assert np.isfinite(got["reopt_error"][0]) and got["reopt_type"][0] in (1, 2, 3)

@@ -155,7 +155,7 @@ def test_output_writers_layout(oracle):
 
 @pytest.mark.parametrize("num_pes", [2, 3])
 def test_cpp_adapters_compile_in_the_reference_include_order(num_pes):
-    """host/kernel.h, complex_kernel.h, predict.h behind a stdafx.h / storage.h with the reference's include guards and global
+    """host/kernel.h, complex_kernel.h, predict.h, opt.h behind a stdafx.h / storage.h with the reference's include guards and global
     names (tests/cpp/ref_env, this image has no Eigen): the reference's call patterns (opt.cpp:74-232, 441-482, 622-719,
     1179-1195; main.cpp:74-101; output.cpp:181-290) compile without redefinitions or ambiguities.  Syntax only: no GPU here."""
     import os
@@ -163,10 +163,11 @@ def test_cpp_adapters_compile_in_the_reference_include_order(num_pes):
     from tests.conftest import ROOT
     cmd = ["g++", "-std=c++20", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", f"-DGPLE_TEST_NUM_PES={num_pes}",
            "-I" + os.path.join(ROOT, "tests", "cpp", "ref_env"), "-I" + os.path.join(ROOT, "gaussian_process_liouville_equation_amd", "host"),
-           os.path.join(ROOT, "tests", "cpp", "dropin_callers.cpp")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-3000:]
-    for header in ("kernel.h", "complex_kernel.h", "predict.h", "gple_host.h"):
+           ]
+    for driver in ("dropin_callers.cpp", "dropin_opt.cpp"):  # main.cpp:66-74 + output.cpp:120-132 on host/opt.h in the second
+        r = subprocess.run(cmd + [os.path.join(ROOT, "tests", "cpp", driver)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+    for header in ("kernel.h", "complex_kernel.h", "predict.h", "gple_host.h", "opt.h"):
         text = open(os.path.join(ROOT, "gaussian_process_liouville_equation_amd", "host", header)).read()
         assert "using namespace" not in text
         for name in ("NumPES =", "NumOffDiagonalElements =", "Dim =", "PhaseDim =", "class QuantumStorage", "calculate_offdiagonal_index("):
