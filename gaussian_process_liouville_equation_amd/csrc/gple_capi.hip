@@ -1994,4 +1994,36 @@ extern "C"
 	{
 		return nlml_predict_impl(ctx, x, 5, X, y, N, Xs, M, flags, mean);
 	}
+
+	/* not part of include/gple.h: instrumented launch of the diagonal-block kernel for probes/diag_probe.py.
+	 * A: 64 x 64 column-major SPD block (host); T out: inv(chol(A)) (host); stamps: 16 cycle-counter values (host). */
+	int gple_debug_potrf_diag(gple_ctx* ctx, const double* A, double* T, long long* stamps, int reps, float* ms_per_launch)
+	{
+		if (!ctx || !A || !T || !stamps) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		Scratch a(ctx), t(ctx), aux(ctx);
+		GPLE_HIP(ctx, a.get(64 * 64));
+		GPLE_HIP(ctx, t.get(64 * 64));
+		GPLE_HIP(ctx, aux.get(32));
+		GPLE_HIP(ctx, hipMemsetAsync(aux.p, 0, 32 * 8, st));
+		GPLE_HIP(ctx, copy_in(st, a.p, A, 64 * 64, false));
+		hipEvent_t e0, e1;
+		GPLE_HIP(ctx, hipEventCreate(&e0));
+		GPLE_HIP(ctx, hipEventCreate(&e1));
+		GPLE_HIP(ctx, debug_potrf_diag(st, a.p, t.p, reinterpret_cast<int*>(aux.p), reinterpret_cast<long long*>(aux.p + 8)));
+		GPLE_HIP(ctx, hipEventRecord(e0, st));
+		for (int i = 0; i < reps; ++i) GPLE_HIP(ctx, debug_potrf_diag(st, a.p, t.p, reinterpret_cast<int*>(aux.p), reinterpret_cast<long long*>(aux.p + 8)));
+		GPLE_HIP(ctx, hipEventRecord(e1, st));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		float ms = 0.f;
+		GPLE_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+		if (ms_per_launch) *ms_per_launch = reps > 0 ? ms / reps : 0.f;
+		(void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+		GPLE_HIP(ctx, hipMemcpy(T, t.p, 64 * 64 * 8, hipMemcpyDeviceToHost));
+		GPLE_HIP(ctx, hipMemcpy(stamps, aux.p + 8, 16 * 8, hipMemcpyDeviceToHost));
+		return GPLE_OK;
+	}
 }

@@ -256,6 +256,276 @@ namespace gple
 			}
 		}
 
+		// ---- diagonal-block kernel: L_jj = chol(A_jj) and T_jj = L_jj^-1 in ONE workgroup ---------------------------------------
+		// The panel sweep above spends ~320 ns per column (64 dependent steps of pivot -> 1/sqrt -> scale -> LDS publish ->
+		// barrier -> LDS read, with up to 63 FMAs per lane behind each), 20 us per panel, and it is the critical path of the fit.
+		// Here only the 64 x 64 diagonal block is factored, 16 columns at a time: inside a 16-column sub-panel one wave holds a
+		// matrix row per lane (16 registers) and takes pivots and multipliers by readlane — no LDS, no barrier on the chain, at
+		// most 15 FMAs per column; between sub-panels the trailing 16 x 16 tiles are updated with MFMAs by all four waves.  The
+		// inverse follows in the same launch: the 16 x 16 diagonal inverses by substitution (one wave each, overlapped with the
+		// next sub-panel's chain), then the 32- and 64-level merges T21 = -T22 (L21 T11) as MFMA tile products.  The rows below
+		// the diagonal block then need no substitution at all: L21 = A21 T_jj^T is a GEMM (potrf_columns).
+		constexpr int DLS = 68; // LDS row stride (doubles): 16-byte aligned rows, fragment reads of 16 rows x 4 k mostly conflict-free
+		typedef double d4v __attribute__((ext_vector_type(4)));
+		// acc(16 x 16, MFMA result layout) += sign * X(16 x K) Y(K x 16); X row-major at xs, Y row-major (YT = false) or given as
+		// its transpose (YT = true: Y[k][j] = ys[j * yld + k])
+		template <bool YT>
+		__device__ __forceinline__ d4v tile_mac(d4v acc, const double* xs, const double* ys, int K, int lane, double sign)
+		{
+			const int fr = lane & 15, fk = lane >> 4;
+			for (int kk = 0; kk < K; kk += 4)
+			{
+				const double x = sign * xs[fr * DLS + kk + fk];
+				const double y = YT ? ys[fr * DLS + kk + fk] : ys[(kk + fk) * DLS + fr];
+				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc, 0, 0, 0);
+			}
+			return acc;
+		}
+		__device__ __forceinline__ d4v tile_load(const double* src, int lane)
+		{
+			const int fr = lane & 15, fk = lane >> 4;
+			d4v a;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) a[r] = src[(fk + 4 * r) * DLS + fr];
+			return a;
+		}
+		__device__ __forceinline__ void tile_store(double* dst, d4v a, int lane)
+		{
+			const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) dst[(fk + 4 * r) * DLS + fr] = a[r];
+		}
+		// columns 16 SP .. 16 SP + 15 of the block: lane = row, pivots and multipliers by readlane.  Nothing is masked: entries
+		// above the diagonal carry garbage that no valid entry ever reads (a multiplier is taken from lane base + j > piv, a
+		// pivot from the diagonal), the diagonal of L is never needed (1 / L_kk goes to rinv), and positivity is checked on
+		// the reciprocals after the sweep.  Software-pipelined by hand: iteration k runs the 1/sqrt chain of column k while the
+		// rank-1 update of column k - 1 is applied to the columns right of k + 1; only the update of column k + 1 itself (the
+		// next pivot column) sits on the chain.  sched_barrier keeps hipcc from hoisting every readlane to the top (211 SGPR
+		// spills and a left-looking chain of k dependent FMAs in front of every pivot in the first version: 16.7 us per block).
+		template <int SP>
+		__device__ __forceinline__ void diag_chain(double* S, double* rinv, int lane, int& first_bad)
+		{
+			constexpr int base = 16 * SP;
+			double p[16], rr[16];
+			double* const row = S + lane * DLS + base;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) p[k] = row[k];
+			double lprev = 0.0;
+#pragma unroll
+			for (int k = 0; k < 16; ++k)
+			{
+				const double d = readlane_f64(p[k], base + k);
+				const double r = rsqrt_newton(d);
+				rr[k] = r;
+				if (k > 0)
+#pragma unroll
+					for (int j = k + 1; j < 16; ++j) p[j] = fma(-lprev, readlane_f64(lprev, base + j), p[j]);
+				const double l = p[k] * r;
+				p[k] = l;
+				if (k + 1 < 16) p[k + 1] = fma(-l, readlane_f64(l, base + k + 1), p[k + 1]);
+				lprev = l;
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			if (lane >= base) // rows above the sub-panel's diagonal tile hold nothing anyone reads (their LDS is scratch space)
+#pragma unroll
+				for (int k = 0; k < 16; ++k) row[k] = p[k];
+			int fb = 0;
+#pragma unroll
+			for (int k = 15; k >= 0; --k) fb = (rr[k] > 0.0 && rr[k] < __builtin_inf()) ? fb : base + k + 1;
+			fb = __builtin_amdgcn_readfirstlane(fb);
+			first_bad = first_bad == 0 ? fb : first_bad;
+			if (lane == 0)
+#pragma unroll
+				for (int k = 0; k < 16; ++k) rinv[base + k] = rr[k];
+		}
+		// trailing tiles (ti, tj), SP < tj <= ti < 4, -= L(ti, SP) L(tj, SP)^T; the tiles of the next sub-panel first
+		__device__ __forceinline__ void diag_update(double* S, int sp, int w, int lane)
+		{
+			int q = 0;
+			for (int tj = sp + 1; tj < 4; ++tj)
+				for (int ti = tj; ti < 4; ++ti, ++q)
+					if ((q & 3) == w)
+					{
+						double* const c = S + ti * 16 * DLS + tj * 16;
+						d4v acc = tile_load(c, lane);
+						acc = tile_mac<true>(acc, S + ti * 16 * DLS + 16 * sp, S + tj * 16 * DLS + 16 * sp, 16, lane, -1.0);
+						tile_store(c, acc, lane);
+					}
+		}
+		// TI(b, b) = L(b, b)^-1 (16 x 16): lane & 15 = column of the inverse, forward substitution down the rows
+		__device__ __forceinline__ void diag_inv16(const double* S, const double* rinv, double* TI, int b, int lane)
+		{
+			const int c = lane & 15;
+			const double* const Lb = S + b * 16 * DLS + b * 16;
+			double x[16];
+#pragma unroll
+			for (int r = 0; r < 16; ++r)
+			{
+				double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+				for (int k = 0; k < r; ++k)
+				{
+					if (k & 1) s1 = fma(-Lb[r * DLS + k], x[k], s1);
+					else s0 = fma(-Lb[r * DLS + k], x[k], s0);
+				}
+				x[r] = (r >= c) ? (s0 + s1) * rinv[b * 16 + r] : 0.0;
+			}
+			if (lane < 16)
+#pragma unroll
+				for (int r = 0; r < 16; ++r) TI[(b * 16 + r) * DLS + b * 16 + c] = x[r];
+		}
+		// A points at block (j0, j0) of the working matrix (column-major, lower part valid); T_jj (ldt) receives inv(L_jj) as a full
+		// 64 x 64 block (zeros above the diagonal).  L_jj itself is not kept: nothing downstream reads a diagonal block of the factor.
+		template <bool PROBE>
+		// Every workgroup factors and inverts the diagonal block for itself (no workgroup ever waits for another) and then turns
+		// its own 64 rows of the panel below, P = A(j0 + 64 + 64 b .., j0 .. j0 + 63), into L21 = P T_jj^T in place (40 MFMAs per
+		// wave); the rows are requested from HBM before the factorisation starts.  Workgroup 0 also stores T_jj.
+		__global__ void __launch_bounds__(256) potrf_diag_kernel(const double* __restrict__ A, long lda, double* __restrict__ T, long ldt, int* __restrict__ info,
+			int j0, long long* __restrict__ stamps, double* __restrict__ P, int below)
+		{
+			int stamp_i = 0;
+			auto stamp = [&]() {
+				if constexpr (PROBE)
+					if (threadIdx.x == 0) stamps[stamp_i++] = static_cast<long long>(__builtin_readcyclecounter());
+			};
+			stamp();
+			__shared__ __attribute__((aligned(16))) double S[NB * DLS];  // A_jj -> L_jj; its upper-right 32 x 32 quadrant: scratch of the last merge
+			__shared__ __attribute__((aligned(16))) double TI[NB * DLS]; // T_jj; its upper-right quadrant: scratch of the two 32-level merges
+			__shared__ double rinv[NB];
+			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+			{
+				const int r = t & 63;
+#pragma unroll
+				for (int q = 0; q < 16; ++q)
+				{
+					const int c = (t >> 6) + 4 * q;
+					S[r * DLS + c] = A[r + static_cast<long>(c) * lda];
+				}
+			}
+			const bool has_rows = static_cast<int>(blockIdx.x) * NB < below; // uniform
+			double* const Pb = P + static_cast<long>(blockIdx.x) * NB;
+			double prow[16];
+			if (has_rows)
+			{
+				const int r = t & 63;
+#pragma unroll
+				for (int q = 0; q < 16; ++q) prow[q] = Pb[r + static_cast<long>((t >> 6) + 4 * q) * lda];
+			}
+			int first_bad = 0;
+			double* const SCR1 = TI + 32; // level-1 scratch: rows 0..15 for the pair (0,1), rows 16..31 for (2,3)
+			double* const SCR2 = S + 32;  // level-2 scratch: 32 x 32
+			// W = L(b+1, b) TI(b, b) -> scratch; TI(b+1, b) = -TI(b+1, b+1) W
+			auto merge1_p1 = [&](int b) {
+				d4v acc = {0.0, 0.0, 0.0, 0.0};
+				acc = tile_mac<false>(acc, S + (b + 1) * 16 * DLS + b * 16, TI + b * 16 * DLS + b * 16, 16, lane, 1.0);
+				tile_store(SCR1 + (b / 2) * 16 * DLS, acc, lane);
+			};
+			auto merge1_p2 = [&](int b) {
+				d4v acc = {0.0, 0.0, 0.0, 0.0};
+				acc = tile_mac<false>(acc, TI + (b + 1) * 16 * DLS + (b + 1) * 16, SCR1 + (b / 2) * 16 * DLS, 16, lane, -1.0);
+				tile_store(TI + (b + 1) * 16 * DLS + b * 16, acc, lane);
+			};
+			// W2(a, b) = sum_k L(2 + a, k) TI(k, b), k >= b (TI(0, 1) is not a tile of the inverse)
+			auto merge2_p1 = [&](int q) {
+				const int a = q >> 1, b = q & 1;
+				d4v acc = {0.0, 0.0, 0.0, 0.0};
+				acc = tile_mac<false>(acc, S + (2 + a) * 16 * DLS + b * 16, TI + b * 16 * DLS + b * 16, 32 - 16 * b, lane, 1.0);
+				tile_store(SCR2 + a * 16 * DLS + b * 16, acc, lane);
+			};
+			// TI(2 + a, b) = -sum_k TI(2 + a, 2 + k) W2(k, b), k <= a
+			auto merge2_p2 = [&](int q) {
+				const int a = q >> 1, b = q & 1;
+				d4v acc = {0.0, 0.0, 0.0, 0.0};
+				acc = tile_mac<false>(acc, TI + (2 + a) * 16 * DLS + 32, SCR2 + b * 16, 16 * (a + 1), lane, -1.0);
+				tile_store(TI + (2 + a) * 16 * DLS + b * 16, acc, lane);
+			};
+			__syncthreads();
+			stamp();
+			if (w == 0) diag_chain<0>(S, rinv, lane, first_bad);
+			__syncthreads();
+			stamp();
+			diag_update(S, 0, w, lane);
+			__syncthreads();
+			stamp();
+			if (w == 0) diag_chain<1>(S, rinv, lane, first_bad);
+			else if (w == 1) diag_inv16(S, rinv, TI, 0, lane);
+			__syncthreads();
+			stamp();
+			diag_update(S, 1, w, lane);
+			__syncthreads();
+			stamp();
+			if (w == 0) diag_chain<2>(S, rinv, lane, first_bad);
+			else if (w == 1) diag_inv16(S, rinv, TI, 1, lane);
+			__syncthreads();
+			stamp();
+			if (w == 0) diag_update(S, 2, 0, lane);
+			else if (w == 1) merge1_p1(0);
+			__syncthreads();
+			stamp();
+			if (w == 0) diag_chain<3>(S, rinv, lane, first_bad);
+			else if (w == 1) merge1_p2(0);
+			else if (w == 2) diag_inv16(S, rinv, TI, 2, lane);
+			__syncthreads();
+			stamp();
+			if (w == 0) diag_inv16(S, rinv, TI, 3, lane);
+			else merge2_p1(w - 1);
+			__syncthreads();
+			stamp();
+			if (w == 0) merge1_p1(2);
+			else if (w == 1) merge2_p1(3);
+			__syncthreads();
+			stamp();
+			if (w == 0) merge1_p2(2);
+			__syncthreads();
+			stamp();
+			merge2_p2(w);
+			if (has_rows)
+			{
+				// L_jj is dead; the panel rows go to S once every wave has finished reading SCR2 (S's upper-right quadrant) in merge2_p2
+				__syncthreads();
+				const int r = t & 63;
+#pragma unroll
+				for (int q = 0; q < 16; ++q) S[r * DLS + (t >> 6) + 4 * q] = prow[q];
+			}
+			__syncthreads();
+			stamp();
+			if (blockIdx.x == 0)
+			{
+				const int r = t & 63;
+#pragma unroll
+				for (int q = 0; q < 16; ++q)
+				{
+					const int c = (t >> 6) + 4 * q;
+					T[r + static_cast<long>(c) * ldt] = c <= r ? TI[r * DLS + c] : 0.0;
+				}
+				if (first_bad != 0 && t == 0) atomicCAS(info, 0, j0 + first_bad); // info starts at 0
+			}
+			stamp();
+			if (has_rows)
+			{
+				// L21(16 w .. 16 w + 15, 16 j ..) = sum_{k <= 16 j + 15} P(., k) T_jj(16 j .., k): wave w owns row tile w of the 64 rows
+				d4v out[4];
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+				{
+					out[j] = (d4v){0.0, 0.0, 0.0, 0.0};
+					out[j] = tile_mac<true>(out[j], S + w * 16 * DLS, TI + j * 16 * DLS, 16 * (j + 1), lane, 1.0);
+				}
+				// the wave's own rows of S are dead once its MFMAs have read them: reuse them to transpose the result for coalesced stores
+#pragma unroll
+				for (int j = 0; j < 4; ++j) tile_store(S + w * 16 * DLS + j * 16, out[j], lane);
+				__syncthreads();
+				const int r = t & 63;
+#pragma unroll
+				for (int q = 0; q < 16; ++q)
+				{
+					const int c = (t >> 6) + 4 * q;
+					Pb[r + static_cast<long>(c) * lda] = S[r * DLS + c];
+				}
+			}
+			stamp();
+		}
+
 		// Tinv_b = L_b^-1 for every 64 x 64 diagonal block b of the factor (one wave per block, all blocks in one launch):
 		// lane j owns column j of the inverse and runs its own forward substitution; row r of L is an LDS broadcast.
 		// Called in place (L == T: the panel kernel leaves L_b in T's diagonal blocks): a block is read completely into LDS
@@ -328,6 +598,16 @@ namespace gple
 		return n >= 2048 ? 256 : 0;
 	}
 
+	// 0: panel sweep (diagonal block re-factored per workgroup, rows below by substitution); 1: diagonal block factored and
+	// inverted by one workgroup (potrf_diag_kernel), rows below as the GEMM A21 T_jj^T
+	static int chol_scheme()
+	{
+		static const int v = [] {
+			const char* e = getenv("GPLE_CHOL_SCHEME");
+			return e ? atoi(e) : 1;
+		}();
+		return v;
+	}
 	static int panel_variant()
 	{
 		static const int v = [] {
@@ -356,7 +636,14 @@ namespace gple
 			const int m = n - j0; // rows of the panel including the diagonal block
 			const int below = m - NB;
 			const int nwg = below > 0 ? (below + PANEL_ROWS - 1) / PANEL_ROWS : 1;
-			if (panel_variant() == 1)
+			if (chol_scheme() == 1)
+			{
+				double* Tjj = T + j0 + static_cast<long>(j0) * ldt;
+				const int ndt = below > 0 ? below / NB : 1;
+				hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(ndt), dim3(256), 0, s, at(j0, j0), lda, Tjj, ldt, info, j0, static_cast<long long*>(nullptr),
+					at(j0 + (below > 0 ? NB : 0), j0), below);
+			}
+			else if (panel_variant() == 1)
 				hipLaunchKernelGGL(potrf_panel16_kernel, dim3(nwg), dim3(P16_THREADS), 0, s, at(j0, j0), lda, m, info, j0, T + j0 + static_cast<long>(j0) * ldt, ldt);
 			else
 				hipLaunchKernelGGL(potrf_panel_kernel, dim3(nwg), dim3(PANEL_THREADS), 0, s, at(j0, j0), lda, m, info, j0, T + j0 + static_cast<long>(j0) * ldt, ldt);
@@ -376,13 +663,20 @@ namespace gple
 		return hipGetLastError();
 	}
 
+	// probe entry (probes/diag_probe.py): one instrumented launch of the diagonal-block kernel on device buffers
+	hipError_t debug_potrf_diag(hipStream_t s, const double* A, double* T, int* info, long long* stamps)
+	{
+		hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), 0, s, A, 64L, T, 64L, info, 0, stamps, const_cast<double*>(A), 0);
+		return hipGetLastError();
+	}
+
 	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info)
 	{
 		if (n % NB) return hipErrorInvalidValue;
 		const hipError_t e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n);
 		if (e != hipSuccess) return e;
 		// the 64 x 64 inverses are only the leaves of the merge tree: one batched launch, off the factorisation's critical path
-		hipLaunchKernelGGL(trinv_diag_kernel, dim3(n / NB), dim3(64), 0, s, T, ldt, T, ldt);
+		if (chol_scheme() != 1) hipLaunchKernelGGL(trinv_diag_kernel, dim3(n / NB), dim3(64), 0, s, T, ldt, T, ldt);
 		return hipGetLastError();
 	}
 
@@ -489,7 +783,7 @@ namespace gple
 		if ((e = hipEventRecord(ctx->side_fork, s)) != hipSuccess) return e;
 		// side stream: T11 = L11^-1 and W = L21 T11, all inputs final
 		if ((e = hipStreamWaitEvent(side, ctx->side_fork, 0)) != hipSuccess) return e;
-		hipLaunchKernelGGL(trinv_diag_kernel, dim3(H / NB), dim3(64), 0, side, T, ldt, T, ldt);
+		if (chol_scheme() != 1) hipLaunchKernelGGL(trinv_diag_kernel, dim3(H / NB), dim3(64), 0, side, T, ldt, T, ldt);
 		if ((e = trtri_lower_from_diag(side, A, lda, T, ldt, H, w_lead)) != hipSuccess) return e;
 		{
 			GemmDesc g{};
@@ -502,7 +796,7 @@ namespace gple
 		// main stream meanwhile: trailing block columns and their inverse
 		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, H, n)) != hipSuccess) return e;
 		double* T22 = T + H + static_cast<long>(H) * ldt;
-		hipLaunchKernelGGL(trinv_diag_kernel, dim3((n - H) / NB), dim3(64), 0, s, T22, ldt, T22, ldt);
+		if (chol_scheme() != 1) hipLaunchKernelGGL(trinv_diag_kernel, dim3((n - H) / NB), dim3(64), 0, s, T22, ldt, T22, ldt);
 		if ((e = trtri_lower_from_diag(s, A + H + static_cast<long>(H) * lda, lda, T22, ldt, n - H, w_trail)) != hipSuccess) return e;
 		// join: T21 = -T22 W
 		if ((e = hipStreamWaitEvent(s, ctx->side_join, 0)) != hipSuccess) return e;

@@ -143,6 +143,7 @@ namespace gple
 	// inv(L_jj) in every diagonal block, i.e. the diagonal blocks of T = L^-1.  info (device int): 0 or 1 + index of the
 	// first non-positive pivot.
 	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info);
+	hipError_t debug_potrf_diag(hipStream_t s, const double* A, double* T, int* info, long long* stamps);
 	// Completes T = L^-1 (lower) given its diagonal blocks; work: at least n*n/4 doubles.
 	hipError_t trtri_lower_from_diag(hipStream_t s, const double* L, long ldl, double* T, long ldt, int n, double* work);
 	// L = chol(A) and T = L^-1 in one go (what a fit needs): potrf_lower + trtri_lower_from_diag, with the inverse of the
