@@ -256,30 +256,42 @@ namespace gple
 			}
 		}
 
-		// ---- diagonal-block kernel: L_jj = chol(A_jj) and T_jj = L_jj^-1 in ONE workgroup ---------------------------------------
+		// ---- diagonal-block kernel: L_jj = chol(A_jj), T_jj = L_jj^-1 and the panel rows below, one launch ----------------------
 		// The panel sweep above spends ~320 ns per column (64 dependent steps of pivot -> 1/sqrt -> scale -> LDS publish ->
 		// barrier -> LDS read, with up to 63 FMAs per lane behind each), 20 us per panel, and it is the critical path of the fit.
-		// Here only the 64 x 64 diagonal block is factored, 16 columns at a time: inside a 16-column sub-panel one wave holds a
-		// matrix row per lane (16 registers) and takes pivots and multipliers by readlane — no LDS, no barrier on the chain, at
-		// most 15 FMAs per column; between sub-panels the trailing 16 x 16 tiles are updated with MFMAs by all four waves.  The
-		// inverse follows in the same launch: the 16 x 16 diagonal inverses by substitution (one wave each, overlapped with the
-		// next sub-panel's chain), then the 32- and 64-level merges T21 = -T22 (L21 T11) as MFMA tile products.  The rows below
-		// the diagonal block then need no substitution at all: L21 = A21 T_jj^T is a GEMM (potrf_columns).
+		// Here the 64 x 64 diagonal block is factored 16 columns at a time by ONE wave with a matrix row per lane and no LDS or
+		// barrier on the chain: every 16-lane DPP row also carries a replica of the 16 x 16 diagonal tile, so that the pivot and
+		// every multiplier L(base + j, k) is a row_newbcast of the replica — one v_fmac_f64_dpp per rank-1 entry instead of two
+		// v_readlane and an FMA (the first version: 240 cycles per column, issue-bound).  Between sub-panels the trailing
+		// 16 x 16 tiles are updated with MFMAs by all four waves.  The inverse is built in the same launch, off the chain: the
+		// 16 x 16 diagonal inverses by substitution (one wave each, again DPP broadcasts, overlapped with the next sub-panel's
+		// chain), the rest by block rows, T(i, b) = -T(i, i) sum_k L(i, k) T(k, b), as MFMA tile products on the idle waves —
+		// everything of block row 3 except the last product is done before its diagonal tile is even factored.  The rows below
+		// the diagonal block then need no substitution: L21 = A21 T_jj^T, 40 MFMAs per wave.
 		constexpr int DLS = 68; // LDS row stride (doubles): 16-byte aligned rows, fragment reads of 16 rows x 4 k mostly conflict-free
 		typedef double d4v __attribute__((ext_vector_type(4)));
-		// acc(16 x 16, MFMA result layout) += sign * X(16 x K) Y(K x 16); X row-major at xs, Y row-major (YT = false) or given as
-		// its transpose (YT = true: Y[k][j] = ys[j * yld + k])
-		template <bool YT>
-		__device__ __forceinline__ d4v tile_mac(d4v acc, const double* xs, const double* ys, int K, int lane, double sign)
+		// acc(16 x 16, MFMA result layout) +-= X(16 x K) Y(K x 16); X row-major at xs, Y row-major (YT = false) or given as its
+		// transpose (YT = true: Y[k][j] = ys[j * DLS + k]).  All operands are requested before the first MFMA; two accumulators.
+		template <bool YT, bool NEG, int K>
+		__device__ __forceinline__ d4v tile_mac(d4v acc, const double* xs, const double* ys, int lane)
 		{
 			const int fr = lane & 15, fk = lane >> 4;
-			for (int kk = 0; kk < K; kk += 4)
+			double x[K / 4], y[K / 4];
+#pragma unroll
+			for (int q = 0; q < K / 4; ++q)
 			{
-				const double x = sign * xs[fr * DLS + kk + fk];
-				const double y = YT ? ys[fr * DLS + kk + fk] : ys[(kk + fk) * DLS + fr];
-				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc, 0, 0, 0);
+				x[q] = xs[fr * DLS + 4 * q + fk];
+				y[q] = YT ? ys[fr * DLS + 4 * q + fk] : ys[(4 * q + fk) * DLS + fr];
 			}
-			return acc;
+			d4v a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int q = 0; q < K / 4; ++q)
+			{
+				const double xv = NEG ? -x[q] : x[q];
+				if ((q & 1) && K > 4) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, y[q], a1, 0, 0, 0);
+				else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, y[q], acc, 0, 0, 0);
+			}
+			return K > 4 ? acc + a1 : acc;
 		}
 		__device__ __forceinline__ d4v tile_load(const double* src, int lane)
 		{
@@ -295,40 +307,82 @@ namespace gple
 #pragma unroll
 			for (int r = 0; r < 4; ++r) dst[(fk + 4 * r) * DLS + fr] = a[r];
 		}
-		// columns 16 SP .. 16 SP + 15 of the block: lane = row, pivots and multipliers by readlane.  Nothing is masked: entries
-		// above the diagonal carry garbage that no valid entry ever reads (a multiplier is taken from lane base + j > piv, a
-		// pivot from the diagonal), the diagonal of L is never needed (1 / L_kk goes to rinv), and positivity is checked on
-		// the reciprocals after the sweep.  Software-pipelined by hand: iteration k runs the 1/sqrt chain of column k while the
-		// rank-1 update of column k - 1 is applied to the columns right of k + 1; only the update of column k + 1 itself (the
-		// next pivot column) sits on the chain.  sched_barrier keeps hipcc from hoisting every readlane to the top (211 SGPR
-		// spills and a left-looking chain of k dependent FMAs in front of every pivot in the first version: 16.7 us per block).
+		// DPP helpers (gfx90a+: 64-bit DPP exists for v_mov_b64 / v_fmac_f64 with row_newbcast only).  A VGPR written by a VALU
+		// instruction needs two wait states before a DPP instruction may read it as its source; hipcc does not look into inline
+		// asm, so values that will be broadcast are produced by dpp_mul (asm) and fenced by dpp_fence (s_nop 1).  volatile asm
+		// statements keep their program order, which is all the ordering this relies on.
+		template <int LANE>
+		__device__ __forceinline__ double dpp_bcast(double v)
+		{
+			double r;
+			asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(LANE));
+			return r;
+		}
+		template <int LANE> // acc += bcast_LANE(src) * mul
+		__device__ __forceinline__ void dpp_fmac(double& acc, double src, double mul)
+		{
+			asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+		}
+		__device__ __forceinline__ double dpp_mul(double a, double b)
+		{
+			double r;
+			asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+			return r;
+		}
+		__device__ __forceinline__ void dpp_fence() { asm volatile("s_nop 1"); }
+		__device__ __forceinline__ void dpp_fence(double& v) { asm volatile("s_nop 1" : "+v"(v)); }
+
+		// columns 16 SP .. 16 SP + 15 of the block.  lane -> matrix row base + lane in p[] (lanes past the last row repeat row 63 and
+		// store nothing) and row base + (lane & 15) of the diagonal tile in q[] (the replica of its DPP row).  Nothing is masked:
+		// entries above the diagonal carry garbage that no valid entry ever reads, the diagonal of L is never needed (1 / L_kk
+		// goes to rinv) and positivity is checked on the reciprocals after the sweep.  Software-pipelined by hand: iteration k
+		// runs the 1/sqrt chain of column k while the rank-1 update of column k - 1 is applied to the columns right of k; only
+		// the update of column k + 1 by column k sits between two pivots.
 		template <int SP>
 		__device__ __forceinline__ void diag_chain(double* S, double* rinv, int lane, int& first_bad)
 		{
 			constexpr int base = 16 * SP;
-			double p[16], rr[16];
-			double* const row = S + lane * DLS + base;
+			const int own = min(base + lane, NB - 1);
+			double p[16], q[16], rr[16];
+			double* const prow = S + own * DLS + base;
+			const double* const qrow = S + (base + (lane & 15)) * DLS + base;
 #pragma unroll
-			for (int k = 0; k < 16; ++k) p[k] = row[k];
-			double lprev = 0.0;
-#pragma unroll
-			for (int k = 0; k < 16; ++k)
+			for (int k = 0; k < 16; ++k) p[k] = prow[k], q[k] = qrow[k];
+			double lq = 0.0, nlq = 0.0, nl = 0.0;
+			[&]<int... Ks>(std::integer_sequence<int, Ks...>)
 			{
-				const double d = readlane_f64(p[k], base + k);
-				const double r = rsqrt_newton(d);
-				rr[k] = r;
-				if (k > 0)
-#pragma unroll
-					for (int j = k + 1; j < 16; ++j) p[j] = fma(-lprev, readlane_f64(lprev, base + j), p[j]);
-				const double l = p[k] * r;
-				p[k] = l;
-				if (k + 1 < 16) p[k + 1] = fma(-l, readlane_f64(l, base + k + 1), p[k + 1]);
-				lprev = l;
-				__builtin_amdgcn_sched_barrier(0);
+				(
+					[&] {
+						constexpr int k = Ks;
+						dpp_fence(q[k]); // q[k] was last written by the fmac at the end of the previous iteration
+						const double d = dpp_bcast<k>(q[k]);
+						const double r = rsqrt_newton(d);
+						rr[k] = r;
+						if constexpr (k > 0)
+							[&]<int... Js>(std::integer_sequence<int, Js...>)
+							{
+								((Js > k ? (dpp_fmac<Js>(q[Js], lq, nlq), dpp_fmac<Js>(p[Js], lq, nl)) : (void)0), ...);
+							}
+							(std::make_integer_sequence<int, 16>{});
+						const double nr = -r;
+						lq = dpp_mul(q[k], r);
+						nlq = q[k] * nr;
+						p[k] = p[k] * r;
+						nl = -p[k];
+						dpp_fence();
+						if constexpr (k + 1 < 16)
+						{
+							dpp_fmac<k + 1>(q[k + 1], lq, nlq);
+							dpp_fmac<k + 1>(p[k + 1], lq, nl);
+						}
+						__builtin_amdgcn_sched_barrier(0);
+					}(),
+					...);
 			}
-			if (lane >= base) // rows above the sub-panel's diagonal tile hold nothing anyone reads (their LDS is scratch space)
+			(std::make_integer_sequence<int, 16>{});
+			if (base + lane < NB)
 #pragma unroll
-				for (int k = 0; k < 16; ++k) row[k] = p[k];
+				for (int k = 0; k < 16; ++k) prow[k] = p[k];
 			int fb = 0;
 #pragma unroll
 			for (int k = 15; k >= 0; --k) fb = (rr[k] > 0.0 && rr[k] < __builtin_inf()) ? fb : base + k + 1;
@@ -338,48 +392,48 @@ namespace gple
 #pragma unroll
 				for (int k = 0; k < 16; ++k) rinv[base + k] = rr[k];
 		}
-		// trailing tiles (ti, tj), SP < tj <= ti < 4, -= L(ti, SP) L(tj, SP)^T; the tiles of the next sub-panel first
-		__device__ __forceinline__ void diag_update(double* S, int sp, int w, int lane)
-		{
-			int q = 0;
-			for (int tj = sp + 1; tj < 4; ++tj)
-				for (int ti = tj; ti < 4; ++ti, ++q)
-					if ((q & 3) == w)
-					{
-						double* const c = S + ti * 16 * DLS + tj * 16;
-						d4v acc = tile_load(c, lane);
-						acc = tile_mac<true>(acc, S + ti * 16 * DLS + 16 * sp, S + tj * 16 * DLS + 16 * sp, 16, lane, -1.0);
-						tile_store(c, acc, lane);
-					}
-		}
-		// TI(b, b) = L(b, b)^-1 (16 x 16): lane & 15 = column of the inverse, forward substitution down the rows
+		// TI(b, b) = L(b, b)^-1 (16 x 16): lane & 15 = row i of the tile, x[] = row i of the inverse.  acc_i[c] collects
+		// sum_{c <= k < i} L(i, k) X(k, c); row k of the inverse, X(k, c) = -acc_k[c] / L(k, k), is broadcast from lane k at step k.
 		__device__ __forceinline__ void diag_inv16(const double* S, const double* rinv, double* TI, int b, int lane)
 		{
-			const int c = lane & 15;
-			const double* const Lb = S + b * 16 * DLS + b * 16;
-			double x[16];
+			const int i = lane & 15;
+			const double* const Lrow = S + (b * 16 + i) * DLS + b * 16;
+			double Lm[16], acc[16];
 #pragma unroll
-			for (int r = 0; r < 16; ++r)
+			for (int k = 0; k < 16; ++k) Lm[k] = i > k ? Lrow[k] : 0.0, acc[k] = 0.0;
+			const double ri = rinv[b * 16 + i], nri = -ri;
+			[&]<int... Ks>(std::integer_sequence<int, Ks...>)
 			{
-				double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+				(
+					[&] {
+						constexpr int k = Ks;
+						double tmp[16];
 #pragma unroll
-				for (int k = 0; k < r; ++k)
-				{
-					if (k & 1) s1 = fma(-Lb[r * DLS + k], x[k], s1);
-					else s0 = fma(-Lb[r * DLS + k], x[k], s0);
-				}
-				x[r] = (r >= c) ? (s0 + s1) * rinv[b * 16 + r] : 0.0;
+						for (int c = 0; c < k; ++c) tmp[c] = dpp_mul(nri, acc[c]);
+						tmp[k] = ri;
+						dpp_fence();
+						[&]<int... Cs>(std::integer_sequence<int, Cs...>)
+						{
+							((Cs <= k ? dpp_fmac<k>(acc[Cs], tmp[Cs], Lm[k]) : (void)0), ...);
+						}
+						(std::make_integer_sequence<int, 16>{});
+					}(),
+					...);
 			}
+			(std::make_integer_sequence<int, 16>{});
 			if (lane < 16)
+			{
+				double* const Trow = TI + (b * 16 + i) * DLS + b * 16;
 #pragma unroll
-				for (int r = 0; r < 16; ++r) TI[(b * 16 + r) * DLS + b * 16 + c] = x[r];
+				for (int c = 0; c < 16; ++c) Trow[c] = c < i ? nri * acc[c] : (c == i ? ri : 0.0);
+			}
 		}
 		// A points at block (j0, j0) of the working matrix (column-major, lower part valid); T_jj (ldt) receives inv(L_jj) as a full
 		// 64 x 64 block (zeros above the diagonal).  L_jj itself is not kept: nothing downstream reads a diagonal block of the factor.
-		template <bool PROBE>
 		// Every workgroup factors and inverts the diagonal block for itself (no workgroup ever waits for another) and then turns
-		// its own 64 rows of the panel below, P = A(j0 + 64 + 64 b .., j0 .. j0 + 63), into L21 = P T_jj^T in place (40 MFMAs per
-		// wave); the rows are requested from HBM before the factorisation starts.  Workgroup 0 also stores T_jj.
+		// its own 64 rows of the panel below, P = A(j0 + 64 + 64 b .., j0 .. j0 + 63), into L21 = P T_jj^T in place; the rows are
+		// requested from HBM before the factorisation starts.  Workgroup 0 also stores T_jj.
+		template <bool PROBE>
 		__global__ void __launch_bounds__(256) potrf_diag_kernel(const double* __restrict__ A, long lda, double* __restrict__ T, long ldt, int* __restrict__ info,
 			int j0, long long* __restrict__ stamps, double* __restrict__ P, int below)
 		{
@@ -389,8 +443,8 @@ namespace gple
 					if (threadIdx.x == 0) stamps[stamp_i++] = static_cast<long long>(__builtin_readcyclecounter());
 			};
 			stamp();
-			__shared__ __attribute__((aligned(16))) double S[NB * DLS];  // A_jj -> L_jj; its upper-right 32 x 32 quadrant: scratch of the last merge
-			__shared__ __attribute__((aligned(16))) double TI[NB * DLS]; // T_jj; its upper-right quadrant: scratch of the two 32-level merges
+			__shared__ __attribute__((aligned(16))) double S[NB * DLS];  // A_jj -> L_jj (strictly lower tiles); later the panel rows
+			__shared__ __attribute__((aligned(16))) double TI[NB * DLS]; // T_jj; tile (i, b), b < i, holds V(i, b) until T(i, b) replaces it
 			__shared__ double rinv[NB];
 			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
 			{
@@ -412,77 +466,77 @@ namespace gple
 				for (int q = 0; q < 16; ++q) prow[q] = Pb[r + static_cast<long>((t >> 6) + 4 * q) * lda];
 			}
 			int first_bad = 0;
-			double* const SCR1 = TI + 32; // level-1 scratch: rows 0..15 for the pair (0,1), rows 16..31 for (2,3)
-			double* const SCR2 = S + 32;  // level-2 scratch: 32 x 32
-			// W = L(b+1, b) TI(b, b) -> scratch; TI(b+1, b) = -TI(b+1, b+1) W
-			auto merge1_p1 = [&](int b) {
-				d4v acc = {0.0, 0.0, 0.0, 0.0};
-				acc = tile_mac<false>(acc, S + (b + 1) * 16 * DLS + b * 16, TI + b * 16 * DLS + b * 16, 16, lane, 1.0);
-				tile_store(SCR1 + (b / 2) * 16 * DLS, acc, lane);
+			auto Sx = [&](int ti, int tj) { return S + ti * 16 * DLS + tj * 16; };
+			auto Tx = [&](int ti, int tj) { return TI + ti * 16 * DLS + tj * 16; };
+			// trailing tile (ti, tj) -= L(ti, sp) L(tj, sp)^T
+			auto upd = [&](int ti, int tj, int sp) {
+				d4v acc = tile_load(Sx(ti, tj), lane);
+				acc = tile_mac<true, true, 16>(acc, Sx(ti, sp), Sx(tj, sp), lane);
+				tile_store(Sx(ti, tj), acc, lane);
 			};
-			auto merge1_p2 = [&](int b) {
+			// V(i, b) (+)= L(i, k) T(k, b), kept in TI's tile (i, b)
+			auto v_acc = [&](int i, int b, int k, bool first) {
 				d4v acc = {0.0, 0.0, 0.0, 0.0};
-				acc = tile_mac<false>(acc, TI + (b + 1) * 16 * DLS + (b + 1) * 16, SCR1 + (b / 2) * 16 * DLS, 16, lane, -1.0);
-				tile_store(TI + (b + 1) * 16 * DLS + b * 16, acc, lane);
+				if (!first) acc = tile_load(Tx(i, b), lane);
+				acc = tile_mac<false, false, 16>(acc, Sx(i, k), Tx(k, b), lane);
+				tile_store(Tx(i, b), acc, lane);
 			};
-			// W2(a, b) = sum_k L(2 + a, k) TI(k, b), k >= b (TI(0, 1) is not a tile of the inverse)
-			auto merge2_p1 = [&](int q) {
-				const int a = q >> 1, b = q & 1;
+			// T(i, b) = -T(i, i) V(i, b), in place
+			auto t_fin = [&](int i, int b) {
 				d4v acc = {0.0, 0.0, 0.0, 0.0};
-				acc = tile_mac<false>(acc, S + (2 + a) * 16 * DLS + b * 16, TI + b * 16 * DLS + b * 16, 32 - 16 * b, lane, 1.0);
-				tile_store(SCR2 + a * 16 * DLS + b * 16, acc, lane);
-			};
-			// TI(2 + a, b) = -sum_k TI(2 + a, 2 + k) W2(k, b), k <= a
-			auto merge2_p2 = [&](int q) {
-				const int a = q >> 1, b = q & 1;
-				d4v acc = {0.0, 0.0, 0.0, 0.0};
-				acc = tile_mac<false>(acc, TI + (2 + a) * 16 * DLS + 32, SCR2 + b * 16, 16 * (a + 1), lane, -1.0);
-				tile_store(TI + (2 + a) * 16 * DLS + b * 16, acc, lane);
+				acc = tile_mac<false, true, 16>(acc, Tx(i, i), Tx(i, b), lane);
+				tile_store(Tx(i, b), acc, lane);
 			};
 			__syncthreads();
 			stamp();
 			if (w == 0) diag_chain<0>(S, rinv, lane, first_bad);
 			__syncthreads();
 			stamp();
-			diag_update(S, 0, w, lane);
+			if (w == 0) upd(1, 1, 0);
+			else if (w == 1) upd(2, 1, 0);
+			else if (w == 2) upd(3, 1, 0);
+			else upd(2, 2, 0);
 			__syncthreads();
 			stamp();
 			if (w == 0) diag_chain<1>(S, rinv, lane, first_bad);
 			else if (w == 1) diag_inv16(S, rinv, TI, 0, lane);
+			else if (w == 2) upd(3, 2, 0);
+			else upd(3, 3, 0);
 			__syncthreads();
 			stamp();
-			diag_update(S, 1, w, lane);
+			if (w == 0) upd(2, 2, 1);
+			else if (w == 1) upd(3, 2, 1);
+			else if (w == 2) upd(3, 3, 1);
+			else v_acc(1, 0, 0, true);
 			__syncthreads();
 			stamp();
 			if (w == 0) diag_chain<2>(S, rinv, lane, first_bad);
 			else if (w == 1) diag_inv16(S, rinv, TI, 1, lane);
+			else if (w == 2) v_acc(2, 0, 0, true);
+			else v_acc(3, 0, 0, true);
 			__syncthreads();
 			stamp();
-			if (w == 0) diag_update(S, 2, 0, lane);
-			else if (w == 1) merge1_p1(0);
+			if (w == 0) upd(3, 3, 2);
+			else if (w == 1) t_fin(1, 0);
+			else if (w == 2) v_acc(2, 1, 1, true);
+			else v_acc(3, 1, 1, true);
 			__syncthreads();
 			stamp();
 			if (w == 0) diag_chain<3>(S, rinv, lane, first_bad);
-			else if (w == 1) merge1_p2(0);
-			else if (w == 2) diag_inv16(S, rinv, TI, 2, lane);
+			else if (w == 1) diag_inv16(S, rinv, TI, 2, lane);
+			else if (w == 2) v_acc(2, 0, 1, false);
+			else v_acc(3, 0, 1, false);
 			__syncthreads();
 			stamp();
 			if (w == 0) diag_inv16(S, rinv, TI, 3, lane);
-			else merge2_p1(w - 1);
+			else if (w == 1) t_fin(2, 0), v_acc(3, 0, 2, false); // LDS operations of one wave complete in order
+			else if (w == 2) t_fin(2, 1), v_acc(3, 1, 2, false);
+			else v_acc(3, 2, 2, true);
 			__syncthreads();
 			stamp();
-			if (w == 0) merge1_p1(2);
-			else if (w == 1) merge2_p1(3);
-			__syncthreads();
-			stamp();
-			if (w == 0) merge1_p2(2);
-			__syncthreads();
-			stamp();
-			merge2_p2(w);
-			if (has_rows)
+			if (w < 3) t_fin(3, w);
+			if (has_rows) // L_jj is dead since the last barrier: the panel rows take its place
 			{
-				// L_jj is dead; the panel rows go to S once every wave has finished reading SCR2 (S's upper-right quadrant) in merge2_p2
-				__syncthreads();
 				const int r = t & 63;
 #pragma unroll
 				for (int q = 0; q < 16; ++q) S[r * DLS + (t >> 6) + 4 * q] = prow[q];
@@ -505,12 +559,10 @@ namespace gple
 			{
 				// L21(16 w .. 16 w + 15, 16 j ..) = sum_{k <= 16 j + 15} P(., k) T_jj(16 j .., k): wave w owns row tile w of the 64 rows
 				d4v out[4];
-#pragma unroll
-				for (int j = 0; j < 4; ++j)
-				{
-					out[j] = (d4v){0.0, 0.0, 0.0, 0.0};
-					out[j] = tile_mac<true>(out[j], S + w * 16 * DLS, TI + j * 16 * DLS, 16 * (j + 1), lane, 1.0);
-				}
+				out[0] = tile_mac<true, false, 16>((d4v){0.0, 0.0, 0.0, 0.0}, S + w * 16 * DLS, TI, lane);
+				out[1] = tile_mac<true, false, 32>((d4v){0.0, 0.0, 0.0, 0.0}, S + w * 16 * DLS, TI + 16 * DLS, lane);
+				out[2] = tile_mac<true, false, 48>((d4v){0.0, 0.0, 0.0, 0.0}, S + w * 16 * DLS, TI + 32 * DLS, lane);
+				out[3] = tile_mac<true, false, 64>((d4v){0.0, 0.0, 0.0, 0.0}, S + w * 16 * DLS, TI + 48 * DLS, lane);
 				// the wave's own rows of S are dead once its MFMAs have read them: reuse them to transpose the result for coalesced stores
 #pragma unroll
 				for (int j = 0; j < 4; ++j) tile_store(S + w * 16 * DLS + j * 16, out[j], lane);

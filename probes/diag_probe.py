@@ -1,6 +1,5 @@
 """Stage-by-stage cycle stamps of potrf_diag_kernel (gple_debug_potrf_diag, not a public entry) + correctness against numpy.
-Stages between stamps: load | chain0 | upd0 | chain1+inv0 | upd1 | chain2+inv1 | upd2+m01a | chain3+m01b+inv2 | inv3+m2a |
-m23a+m2a' | m23b | m2b | store."""
+Stages between stamps: see `names`."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,8 +21,8 @@ assert rc == 0, rc
 ref = np.linalg.inv(np.linalg.cholesky(A))
 print("max |T - inv(chol(A))| =", np.abs(T - ref).max(), " scale", np.abs(ref).max())
 print("us per launch (back to back):", ms.value * 1e3)
-names = "load chain0 upd0 chain1+inv0 upd1 chain2+inv1 upd2+m01a chain3+m01b+inv2 inv3+m2a m23a+m2a m23b m2b store".split()
-d = np.diff(stamps[:14])
+names = "load chain0 upd0 chain1+inv0 upd1 chain2+inv1 upd2+T10 chain3+inv2 inv3+row3 T3x storeT trsm".split()
+d = np.diff(stamps[:13])
 for n, c in zip(names, d):
     print(f"{n:>18}: {c:7d} cycles")
-print("total", stamps[13] - stamps[0], "shader clock cycles (s_memtime)")
+print("total", stamps[12] - stamps[0], "shader clock cycles (s_memtime)")
