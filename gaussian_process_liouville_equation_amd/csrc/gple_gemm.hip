@@ -94,7 +94,10 @@ namespace gple
 			double* const Bs = lds + 2 * BK * AS;
 
 			const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
-			const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+			// K_LE_M: the k-range of a tile grows with its row block; workgroups are dispatched in blockIdx.x order, so the row
+			// blocks are walked from the bottom up — the longest tiles start first and the short ones fill the tail
+			const int bx = g.krange == K_LE_M ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+			const int m0 = bx * BM, n0 = blockIdx.y * BN;
 			if (g.lower_only && n0 >= m0 + BM) return;
 			int kb = 0, ke = g.K;
 			if (g.krange == K_GE_N) kb = n0;
@@ -203,7 +206,10 @@ namespace gple
 			double* const Bs = lds + DEPTH * BK * AS;
 
 			const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
-			const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+			// K_LE_M: the k-range of a tile grows with its row block; workgroups are dispatched in blockIdx.x order, so the row
+			// blocks are walked from the bottom up — the longest tiles start first and the short ones fill the tail
+			const int bx = g.krange == K_LE_M ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+			const int m0 = bx * BM, n0 = blockIdx.y * BN;
 			if (g.lower_only && n0 >= m0 + BM) return;
 			int kb = 0, ke = g.K;
 			if (g.krange == K_GE_N) kb = n0;
@@ -309,6 +315,129 @@ namespace gple
 					}
 		}
 
+		// Latency-bound GEMMs (merge-tree levels on a few dozen 64-tiles, K = 64 trailing updates): a 64 x 64 tile with a long
+		// k-range is MFMA-bound on ONE compute unit (0.43 us per k-step of 16) while most of the chip idles.  Here a workgroup
+		// owns a 32 x 32 tile and its four waves split the k-range between them (four times the workgroups, a quarter of the
+		// dependent k-steps); the partial sums meet in LDS and are added in a fixed order, so the result does not depend on
+		// timing.  Operands go straight from L2 into MFMA fragments (no LDS staging, no barrier in the k-loop): with the k index
+		// of sub-step s taken as k0 + 4 (lane >> 4) + s, a k-major operand is one 32-byte load per lane and 16 k.
+		template <bool KMAJOR>
+		struct FragLoader
+		{
+			double v[2][4]; // [16-row half][sub-step]
+			__device__ __forceinline__ void load(const double* __restrict__ base, long ld, int r0, int k0, int fr, int fk)
+			{
+#pragma unroll
+				for (int i = 0; i < 2; ++i)
+				{
+					if constexpr (KMAJOR)
+					{
+						const d4 x = *reinterpret_cast<const d4*>(base + k0 + 4 * fk + static_cast<long>(r0 + 16 * i + fr) * ld);
+						v[i][0] = x.x, v[i][1] = x.y, v[i][2] = x.z, v[i][3] = x.w;
+					}
+					else
+					{
+#pragma unroll
+						for (int s = 0; s < 4; ++s) v[i][s] = base[r0 + 16 * i + fr + static_cast<long>(k0 + 4 * fk + s) * ld];
+					}
+				}
+			}
+		};
+		template <bool AK, bool BKM>
+		__global__ void __launch_bounds__(256, 2) gemm_f64_splitk_kernel(const GemmDesc g)
+		{
+			constexpr int BT = 32;
+			__shared__ __attribute__((aligned(16))) double red[4][BT * BT];
+			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+			const int fr = lane & 15, fk = lane >> 4;
+			const int m0 = blockIdx.x * BT, n0 = blockIdx.y * BT;
+			if (g.lower_only && n0 >= m0 + BT) return;
+			int kb = 0, ke = g.K;
+			if (g.krange == K_GE_N) kb = n0;
+			else if (g.krange == K_LE_M) ke = min(g.K, m0 + BT);
+			else if (g.krange == K_GE_MAX_MN) kb = max(m0, n0);
+			kb = kb / BK * BK;
+			const int ng = (ke - kb + BK - 1) / BK;
+			const int g_begin = w * ng / 4, g_end = (w + 1) * ng / 4; // this wave's k-groups of 16
+
+			const double* __restrict__ A = g.A + blockIdx.z * g.strideA;
+			const double* __restrict__ B = g.B + blockIdx.z * g.strideB;
+			double* __restrict__ C = g.C + blockIdx.z * g.strideC;
+			const double alpha = g.alpha, beta = g.beta;
+			double cold[4];
+			if (beta != 0.0)
+#pragma unroll
+				for (int q = 0; q < 4; ++q)
+				{
+					const int e = t + 256 * q;
+					cold[q] = C[m0 + (e & 31) + static_cast<long>(n0 + (e >> 5)) * g.ldc];
+				}
+
+			d4 acc[2][2];
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+#pragma unroll
+				for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+			FragLoader<AK> fa[2];
+			FragLoader<BKM> fb[2];
+			auto compute = [&](const FragLoader<AK>& a, const FragLoader<BKM>& b) {
+#pragma unroll
+				for (int s = 0; s < 4; ++s)
+#pragma unroll
+					for (int i = 0; i < 2; ++i)
+#pragma unroll
+						for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b.v[j][s], a.v[i][s], acc[i][j], 0, 0, 0);
+			};
+			if (g_begin < g_end)
+			{
+				fa[0].load(A, g.lda, m0, kb + g_begin * BK, fr, fk);
+				fb[0].load(B, g.ldb, n0, kb + g_begin * BK, fr, fk);
+			}
+			for (int gi = g_begin; gi < g_end; gi += 2)
+			{
+				if (gi + 1 < g_end)
+				{
+					fa[1].load(A, g.lda, m0, kb + (gi + 1) * BK, fr, fk);
+					fb[1].load(B, g.ldb, n0, kb + (gi + 1) * BK, fr, fk);
+				}
+				compute(fa[0], fb[0]);
+				if (gi + 1 < g_end)
+				{
+					if (gi + 2 < g_end)
+					{
+						fa[0].load(A, g.lda, m0, kb + (gi + 2) * BK, fr, fk);
+						fb[0].load(B, g.ldb, n0, kb + (gi + 2) * BK, fr, fk);
+					}
+					compute(fa[1], fb[1]);
+				}
+			}
+			// result layout of the MFMA (first operand = B rows): D[n = (lane >> 4) + 4 r][m = lane & 15]
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+#pragma unroll
+				for (int j = 0; j < 2; ++j)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) red[w][(16 * j + fk + 4 * r) * BT + 16 * i + fr] = acc[i][j][r];
+			__syncthreads();
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+			{
+				const int e = t + 256 * q;
+				double val = alpha * (((red[0][e] + red[1][e]) + red[2][e]) + red[3][e]);
+				if (beta != 0.0) val += beta * cold[q];
+				C[m0 + (e & 31) + static_cast<long>(n0 + (e >> 5)) * g.ldc] = val;
+			}
+		}
+		hipError_t launch_splitk(hipStream_t s, const GemmDesc& d)
+		{
+			if (d.M % 32 || d.N % 32 || d.K % BK || d.M <= 0 || d.N <= 0 || d.batch <= 0 || d.c_trans) return hipErrorInvalidValue;
+			const dim3 grid(d.M / 32, d.N / 32, d.batch), block(256);
+			if (!d.a_kmajor && !d.b_kmajor) hipLaunchKernelGGL((gemm_f64_splitk_kernel<false, false>), grid, block, 0, s, d);
+			else if (!d.a_kmajor && d.b_kmajor) hipLaunchKernelGGL((gemm_f64_splitk_kernel<false, true>), grid, block, 0, s, d);
+			else return hipErrorInvalidValue;
+			return hipGetLastError();
+		}
+
 		template <int T>
 		hipError_t launch_tile(hipStream_t s, const GemmDesc& d)
 		{
@@ -344,12 +473,23 @@ namespace gple
 			const char* e = getenv("GPLE_GEMM_128_MIN_TILES_TRI");
 			return e ? atol(e) : 4096L;
 		}();
+		// few 64-tiles: the split-k kernel (32 x 32 tiles, four waves on the k-range) gets four times as many workgroups going
+		static const long max_splitk = [] {
+			const char* e = getenv("GPLE_GEMM_SPLITK_MAX_TILES");
+			return e ? atol(e) : 256L;
+		}();
+		if ((m / 64) * (n / 64) * batch <= max_splitk) return 32;
 		if (m % 128 || n % 128) return 64;
 		return (m / 128) * (n / 128) * batch >= (triangular ? min_tri : min_dense) ? 128 : 64;
 	}
 
 	hipError_t launch_gemm(hipStream_t s, const GemmDesc& d, int tile)
 	{
+		if (tile == 32)
+		{
+			if (!d.c_trans && !d.a_kmajor) return launch_splitk(s, d);
+			tile = 64; // operand layouts the split-k kernel is not instantiated for
+		}
 		return tile == 128 ? launch_tile<128>(s, d) : launch_tile<64>(s, d);
 	}
 } // namespace gple

@@ -131,7 +131,8 @@ namespace gple
 		int lower_only; // only tiles with m0 + BM > n0 are computed (symmetric / triangular results)
 		bool a_kmajor, b_kmajor, c_trans;
 	};
-	// tile: 64 (64x64 per workgroup) or 128 (128x128 per workgroup)
+	// tile: 64 (64x64 per workgroup), 128 (128x128 per workgroup) or 32 (32x32 per workgroup, the four waves split the k-range:
+	// for latency-bound problems of a few dozen 64-tiles; falls back to 64 for operand layouts it is not instantiated for)
 	hipError_t launch_gemm(hipStream_t s, const GemmDesc& d, int tile);
 	// tile size for an m x n (x batch) result: 128 once there are enough 128-tiles to give every CU two workgroups
 	int gemm_pick_tile(long m, long n, long batch, bool triangular);
