@@ -802,129 +802,16 @@ namespace gple
 		if (H <= 0 || H >= n) H = nblocks / 2 * NB;
 		return H;
 	}
-	// ---- eager merge tree ---------------------------------------------------------------------------------------------------
-	// T = L^-1 by the binary tree over 64-column blocks: node [lo, hi) with split mid owns W = L(right, left) T(left, left) and
-	// T(right, left) = -T(right, right) W.  W only needs the LEFT half finished, so it runs on the side stream as soon as panel
-	// mid - 1 is done, and so does the second product of every node that ends before the last block.  What is left for the main
-	// stream after the last panel is the spine — one product per level, n / 128 ... n / 2 wide — instead of the whole tree of the
-	// trailing half plus the root's second product.
-	struct TreeNode
-	{
-		int lo, mid, hi; // in blocks of NB
-		size_t woff;     // offset of W in the work buffer
-	};
-	static void build_tree(int lo, int hi, std::vector<TreeNode>& nodes, size_t& woff) // post-order: children before parents
-	{
-		if (hi - lo < 2) return;
-		int p = 1;
-		while (2 * p < hi - lo) p *= 2; // largest power of two below the width (half of it for a power of two)
-		const int mid = lo + p;
-		build_tree(lo, mid, nodes, woff);
-		build_tree(mid, hi, nodes, woff);
-		nodes.push_back({lo, mid, hi, woff});
-		woff += static_cast<size_t>(hi - mid) * (mid - lo) * NB * NB;
-	}
-	static int chol_eager()
-	{
-		static const int v = [] {
-			const char* e = getenv("GPLE_CHOL_EAGER");
-			return e ? atoi(e) : 1;
-		}();
-		return v;
-	}
-	// the main stream hands finished block columns to the side stream every `stride` panels (an event record costs the main
-	// stream about a microsecond); products that become ready after the last hand-over run on the main stream
-	static int chol_eager_stride(int nblocks)
-	{
-		static const int forced = [] {
-			const char* e = getenv("GPLE_CHOL_EAGER_STRIDE");
-			return e ? atoi(e) : 0;
-		}();
-		if (forced > 0) return forced;
-		return nblocks <= 16 ? 1 : (nblocks <= 32 ? 2 : 4);
-	}
 	size_t chol_inverse_work_doubles(int n)
 	{
 		// last merge: W = L21 T11, (n - H) x H; a tree over h columns needs at most h^2 / 4 (one pair spanning everything)
 		const size_t H = static_cast<size_t>(chol_split_point(n)), R = static_cast<size_t>(n) - H;
-		const size_t split = R * H + H * H / 4 + R * R / 4 + static_cast<size_t>(n) * static_cast<size_t>(n) / 4 + 64; // last term: the unsplit path
-		std::vector<TreeNode> nodes;
-		size_t eager = 0;
-		build_tree(0, n / NB, nodes, eager);
-		return std::max(split, eager + 64);
-	}
-	static hipError_t tree_w(hipStream_t s, const TreeNode& nd, const double* L, long ldl, double* T, long ldt, double* work)
-	{
-		const long lo = static_cast<long>(nd.lo) * NB, mid = static_cast<long>(nd.mid) * NB, hi = static_cast<long>(nd.hi) * NB;
-		GemmDesc g{};
-		g.A = L + mid + lo * ldl, g.lda = ldl, g.B = T + lo + lo * ldt, g.ldb = ldt, g.C = work + nd.woff, g.ldc = hi - mid;
-		g.M = static_cast<int>(hi - mid), g.N = static_cast<int>(mid - lo), g.K = g.N, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
-		g.krange = K_GE_N, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
-		return launch_gemm(s, g, gemm_pick_tile(g.M, g.N, 1, true));
-	}
-	static hipError_t tree_t(hipStream_t s, const TreeNode& nd, double* T, long ldt, double* work)
-	{
-		const long lo = static_cast<long>(nd.lo) * NB, mid = static_cast<long>(nd.mid) * NB, hi = static_cast<long>(nd.hi) * NB;
-		GemmDesc g{};
-		g.A = T + mid + mid * ldt, g.lda = ldt, g.B = work + nd.woff, g.ldb = hi - mid, g.C = T + mid + lo * ldt, g.ldc = ldt;
-		g.M = static_cast<int>(hi - mid), g.N = static_cast<int>(mid - lo), g.K = g.M, g.batch = 1, g.alpha = -1.0, g.beta = 0.0;
-		g.krange = K_LE_M, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
-		return launch_gemm(s, g, gemm_pick_tile(g.M, g.N, 1, true));
-	}
-	static hipError_t chol_inverse_eager(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work)
-	{
-		const int nb = n / NB;
-		std::vector<TreeNode> nodes;
-		size_t total = 0;
-		build_tree(0, nb, nodes, total);
-		hipError_t e;
-		if (!ctx->side_stream)
-		{
-			if ((e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)) != hipSuccess) return e;
-			if ((e = hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming)) != hipSuccess) return e;
-			if ((e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming)) != hipSuccess) return e;
-		}
-		hipStream_t side = ctx->side_stream;
-		const int stride = chol_eager_stride(nb);
-		const int last_handover = (nb - 1) / stride * stride; // block columns [0, last_handover) reach the side stream
-		// products in issue order: for every boundary b, first the second products of the nodes ending at b (small to large: a
-		// node's right child ends where it ends), then the first product of the node split at b
-		auto issue_ready = [&](hipStream_t st, int b_from, int b_to) -> hipError_t { // boundaries in (b_from, b_to]
-			for (int b = b_from + 1; b <= b_to; ++b)
-			{
-				for (const TreeNode& nd : nodes) // post-order = ascending size among the nodes that share `hi`
-					if (nd.hi == b && b < nb)
-						if ((e = tree_t(st, nd, T, ldt, work)) != hipSuccess) return e;
-				for (const TreeNode& nd : nodes)
-					if (nd.mid == b)
-						if ((e = tree_w(st, nd, A, lda, T, ldt, work)) != hipSuccess) return e;
-			}
-			return hipSuccess;
-		};
-		int handed = 0;
-		bool side_used = false;
-		for (int b = stride; b <= last_handover; b += stride)
-		{
-			if ((e = potrf_columns(s, A, lda, n, T, ldt, info, (b - stride) * NB, b * NB)) != hipSuccess) return e;
-			if ((e = hipEventRecord(ctx->side_fork, s)) != hipSuccess) return e;
-			if ((e = hipStreamWaitEvent(side, ctx->side_fork, 0)) != hipSuccess) return e;
-			if ((e = issue_ready(side, handed, b)) != hipSuccess) return e;
-			handed = b, side_used = true;
-		}
-		if (side_used && (e = hipEventRecord(ctx->side_join, side)) != hipSuccess) return e;
-		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, handed * NB, n)) != hipSuccess) return e;
-		if (side_used && (e = hipStreamWaitEvent(s, ctx->side_join, 0)) != hipSuccess) return e;
-		if ((e = issue_ready(s, handed, nb - 1)) != hipSuccess) return e; // what became ready after the last hand-over
-		for (const TreeNode& nd : nodes)                                    // the spine
-			if (nd.hi == nb)
-				if ((e = tree_t(s, nd, T, ldt, work)) != hipSuccess) return e;
-		return hipGetLastError();
+		return R * H + H * H / 4 + R * R / 4 + static_cast<size_t>(n) * static_cast<size_t>(n) / 4 + 64; // last term: the unsplit path
 	}
 	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work)
 	{
 		if (n % NB) return hipErrorInvalidValue;
 		const int nblocks = n / NB;
-		if (chol_eager() && chol_scheme() == 1 && nblocks >= 4) return chol_inverse_eager(ctx, s, A, lda, n, T, ldt, info, work);
 		if (n < chol_overlap_min_n() || nblocks < 4)
 		{
 			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info);
