@@ -680,6 +680,8 @@ namespace gple
 			g.A = at(r0, k0), g.lda = lda, g.B = at(r0, k0), g.ldb = lda, g.C = at(r0, r0), g.ldc = lda;
 			g.M = m, g.N = ncols, g.K = K, g.batch = 1, g.alpha = -1.0, g.beta = 1.0, g.krange = K_FULL, g.lower_only = 1;
 			g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
+			// (128-tiles by the dense rule — every computed tile has the same k-range here — measured slower: 2.73 vs 2.67 ms at
+			// n = 4096, 12.25 vs 11.16 at 8192; K = 256 is too short for that kernel's two-slab pipeline)
 			return launch_gemm(s, g, gemm_pick_tile(m, ncols, 1, true));
 		};
 		for (int j0 = j_begin; j0 < j_end; j0 += NB)
