@@ -3,8 +3,8 @@
 // Replaces the reference's Eigen::LDLT + solve(Identity) (kernel.cpp:281-283; complex_kernel.cpp:264-266).
 // The kernel matrices of this path are SPD by construction (sf^2 sn^2 ridge, opt.cpp:27), and Eigen's LDLT picks
 // its pivots from the not-yet-updated diagonal, which is constant here — i.e. the reference itself runs
-// unpivoted.  We therefore factor K = L L^T (right-looking, 64-wide panels), form T = L^-1 by a pairwise merge
-// tree of MFMA GEMMs, and only on request W = K^-1 = T^T T.  A non-positive pivot does not abort: sqrt() yields
+// unpivoted.  We therefore factor K = L L^T (right-looking, 64-wide panels; the diagonal blocks leave the panel step
+// already inverted), form T = L^-1 by a pairwise merge tree of MFMA GEMMs, and only on request W = K^-1 = T^T T.  A non-positive pivot does not abort: sqrt() yields
 // NaN which propagates into every output, and *info records the first offending column (reference behaviour:
 // LDLT::info() is never checked, NaN/Inf are clamped later by opt.cpp:420-431).
 #include <algorithm>
@@ -20,15 +20,6 @@ namespace gple
 	{
 		constexpr int NB = CHOL_NB; // 64
 
-		constexpr int LR = NB + 2; // LDS row stride (doubles): 16-byte aligned rows, rows 4 banks apart
-		constexpr int PANEL_THREADS = 128;          // wave 0: the diagonal block; wave 1: 64 panel rows
-		constexpr int PANEL_ROWS = PANEL_THREADS - 64; // rows below the diagonal block per workgroup
-
-		__device__ __forceinline__ double readlane_f64(double v, int lane)
-		{
-			const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-			return __hiloint2double(hi, lo);
-		}
 		// 1/sqrt(d) to full precision: hardware estimate + two Newton steps (sqrt + divide cost ~40 fp64 instructions)
 		__device__ __forceinline__ double rsqrt_newton(double d)
 		{
@@ -38,228 +29,9 @@ namespace gple
 			return r;
 		}
 
-		// ---- broadcast reads of one scaled column, issued by hand -----------------------------------------------------------
-		// In the rank-1 update every lane needs the same 63-k column entries.  Left to itself hipcc keeps about three
-		// ds_read_b128 in flight there and exposes the LDS latency sixteen times per column (measured: 970 cycles per
-		// column, probes/panel_probe.hip).  The reads are therefore issued from inline asm in chunks of eight (16 entries),
-		// two chunks in flight, with explicit s_waitcnt; the "+v" operands of the wait tie the consumers to it.  LDS
-		// operations return in order, so compiler-issued LDS traffic in between can only make a wait longer, never too short.
-		typedef double v2f64 __attribute__((ext_vector_type(2)));
-		struct Chunk
-		{
-			v2f64 c[8];
-		};
-		template <int OFF>
-		__device__ __forceinline__ void lds_read8(Chunk& q, unsigned addr)
-		{
-			asm volatile("ds_read_b128 %0, %8 offset:%9\n"
-						 "ds_read_b128 %1, %8 offset:%9+16\n"
-						 "ds_read_b128 %2, %8 offset:%9+32\n"
-						 "ds_read_b128 %3, %8 offset:%9+48\n"
-						 "ds_read_b128 %4, %8 offset:%9+64\n"
-						 "ds_read_b128 %5, %8 offset:%9+80\n"
-						 "ds_read_b128 %6, %8 offset:%9+96\n"
-						 "ds_read_b128 %7, %8 offset:%9+112\n"
-						 : "=&v"(q.c[0]), "=&v"(q.c[1]), "=&v"(q.c[2]), "=&v"(q.c[3]), "=&v"(q.c[4]), "=&v"(q.c[5]), "=&v"(q.c[6]), "=&v"(q.c[7])
-						 : "v"(addr), "n"(OFF));
-		}
-		template <int N>
-		__device__ __forceinline__ void lds_wait(Chunk& q)
-		{
-			asm volatile("s_waitcnt lgkmcnt(%8)"
-						 : "+v"(q.c[0]), "+v"(q.c[1]), "+v"(q.c[2]), "+v"(q.c[3]), "+v"(q.c[4]), "+v"(q.c[5]), "+v"(q.c[6]), "+v"(q.c[7])
-						 : "n"(N));
-		}
-		// a[j] -= l * column[j] for the entries j > K of chunk C (entries 16 C .. 16 C + 15)
-		template <int K, int C>
-		__device__ __forceinline__ void apply_chunk(double (&a)[NB], const Chunk& q, double l)
-		{
-#pragma unroll
-			for (int i = 0; i < 8; ++i)
-			{
-				const int j = 16 * C + 2 * i;
-				if (j > K) a[j] = fma(-l, q.c[i].x, a[j]);
-				if (j + 1 > K) a[j + 1] = fma(-l, q.c[i].y, a[j + 1]);
-			}
-		}
-		template <int N>
-		__device__ __forceinline__ void lds_wait_scalar(double& r)
-		{
-			asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N));
-		}
-
-		// One column of the panel sweep.  All waves run the same instruction stream (no branches: control flow between
-		// the unrolled columns makes hipcc spill kilobytes per lane); stores only wave 0 should make go to a dump slot.
-		template <int K>
-		__device__ __forceinline__ void panel_column(double (&a)[NB], double (*col)[NB + 2], double* dump, int lane, bool diag, int& first_bad)
-		{
-			double* const cb = &col[K & 1][0];
-			double* const my_col = diag ? &cb[lane] : &dump[threadIdx.x];
-			double* const my_r = (diag && lane == 0) ? &cb[NB] : &dump[threadIdx.x];
-			const double d = readlane_f64(a[K], K); // the pivot in wave 0; a harmless number in the other waves
-			first_bad = (first_bad == 0 && !(d > 0.0)) ? K + 1 : first_bad;
-			const double r0 = rsqrt_newton(d); // NaN for d <= 0: propagates, like the sqrt of a negative pivot
-			double sd = d * r0;
-			sd = fma(fma(-sd, sd, d), 0.5 * r0, sd); // sqrt(d) with a correction step
-			*my_col = lane == K ? sd : (lane > K ? a[K] * r0 : 0.0);
-			*my_r = r0;
-			__syncthreads(); // the only barrier of the column: col[] is double-buffered
-
-			// 1/L_kk and the first chunk of the column are requested together (one LDS round trip, not two); from then on
-			// two chunks are in flight while the previous one is applied
-			const unsigned addr = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) double*)cb));
-			constexpr int CF = (K + 1) / 16; // first chunk holding an entry > K
-			constexpr bool ANY = K + 1 < NB;
-			double r;
-			asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(NB * 8));
-			Chunk q0, q1;
-			if constexpr (ANY) lds_read8<CF * 128>(q0, addr);
-			lds_wait_scalar<ANY ? 8 : 0>(r);
-			const double lp = a[K] * r;
-			const double l = diag ? (lane == K ? sd : (lane > K ? lp : 0.0)) : lp;
-			a[K] = l;
-			if constexpr (ANY)
-			{
-				if constexpr (CF + 1 < 4) lds_read8<(CF + 1) * 128>(q1, addr);
-				lds_wait<(CF + 1 < 4) ? 8 : 0>(q0);
-				apply_chunk<K, CF>(a, q0, l);
-				if constexpr (CF + 2 < 4) lds_read8<(CF + 2) * 128>(q0, addr);
-				if constexpr (CF + 1 < 4)
-				{
-					lds_wait<(CF + 2 < 4) ? 8 : 0>(q1);
-					apply_chunk<K, CF + 1>(a, q1, l);
-					if constexpr (CF + 3 < 4) lds_read8<(CF + 3) * 128>(q1, addr);
-				}
-				if constexpr (CF + 2 < 4)
-				{
-					lds_wait<(CF + 3 < 4) ? 8 : 0>(q0);
-					apply_chunk<K, CF + 2>(a, q0, l);
-				}
-				if constexpr (CF + 3 < 4)
-				{
-					lds_wait<0>(q1);
-					apply_chunk<K, CF + 3>(a, q1, l);
-				}
-			}
-		}
-		template <int... Ks>
-		__device__ __forceinline__ void panel_columns(double (&a)[NB], double (*col)[NB + 2], double* dump, int lane, bool diag, int& first_bad,
-			std::integer_sequence<int, Ks...>)
-		{
-			(panel_column<Ks>(a, col, dump, lane, diag, first_bad), ...);
-		}
-
-		// Panel factorisation: the 64 x 64 diagonal block is factored and, in the same sweep, applied to the rows below
-		// (P <- P L_jj^-T by substitution), one matrix row per lane with its 64 panel entries in registers.  Wave 0 of every
-		// workgroup owns the diagonal block — re-factored redundantly per workgroup, so workgroups never synchronise —
-		// wave 1 owns 64 panel rows.  Per column: wave 0 takes the pivot by readlane and publishes the scaled column with
-		// 1/L_kk next to it; after the barrier every lane scales its own entry and applies the rank-1 update to its row.
-		// A points at block (j0, j0); m = rows from j0 to the end of the matrix (multiple of 64).
-		// The factored diagonal block goes to D (ldd), NOT back into A: every workgroup reads A's diagonal block when it starts,
-		// and a workgroup that is dispatched late (other streams keeping CUs busy) must still find it unfactored.  Writing it in
-		// place was a race between workgroup 0's stores and late workgroups' loads — invisible on an otherwise idle GPU.
-		__global__ void __launch_bounds__(PANEL_THREADS) potrf_panel_kernel(double* __restrict__ A, long lda, int m, int* __restrict__ info, int j0,
-			double* __restrict__ D, long ldd)
-		{
-			__shared__ __attribute__((aligned(16))) double col[2][NB + 2];
-			__shared__ double dump[PANEL_THREADS];
-			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-			const bool diag = w == 0;
-			const int row = diag ? lane : NB + blockIdx.x * PANEL_ROWS + (w - 1) * 64 + lane;
-			const bool valid = row < m;
-			double a[NB];
-			const double* __restrict__ src = A + (valid ? row : 0);
-#pragma unroll
-			for (int j = 0; j < NB; ++j) a[j] = src[static_cast<long>(j) * lda];
-			int first_bad = 0;
-			panel_columns(a, col, dump, lane, diag, first_bad, std::make_integer_sequence<int, NB>{});
-			if (first_bad != 0 && threadIdx.x == 0 && blockIdx.x == 0) atomicCAS(info, 0, j0 + first_bad); // info starts at 0
-			if (valid && (!diag || blockIdx.x == 0))
-			{
-				double* __restrict__ dst = diag ? D + row : A + row;
-				const long ld = diag ? ldd : lda;
-#pragma unroll
-				for (int j = 0; j < NB; ++j) dst[static_cast<long>(j) * ld] = a[j];
-			}
-		}
-
-		// ---- column-split panel kernel -----------------------------------------------------------------------------------
-		// The sweep above keeps a whole 64-entry row per lane, so the wave that owns the diagonal block issues up to 63 fp64
-		// FMAs (8 cycles each) per column on top of the pivot chain: ~700 cycles per column, issue-bound.  Here the 64 columns
-		// of a row block are dealt out to four waves of 16 columns: per column every wave applies at most 16 FMAs, and only
-		// the wave that owns the pivot column runs the 1/sqrt chain.  Workgroup = 8 waves: waves 0-3 hold the diagonal block
-		// (re-factored per workgroup, as above), waves 4-7 hold 64 rows below it; lane = row, one barrier per column with the
-		// published column double-buffered in LDS.
-		constexpr int P16_THREADS = 512, P16_COLS = 16;
-		template <int K>
-		__device__ __forceinline__ void panel16_column(double (&a)[P16_COLS], double (*colD)[NB + 2], double (*colB)[NB], double* rinv, int lane, int role,
-			int cg, int& first_bad)
-		{
-			constexpr int G = K / P16_COLS, C = K % P16_COLS, BUF = K & 1;
-			if (cg == G) // uniform per wave: this wave owns column K of its row block
-			{
-				if (role == 0)
-				{
-					const double d = readlane_f64(a[C], K);
-					first_bad = (first_bad == 0 && !(d > 0.0)) ? K + 1 : first_bad;
-					const double r0 = rsqrt_newton(d); // NaN for d <= 0: propagates, like the sqrt of a negative pivot
-					double sd = d * r0;
-					sd = fma(fma(-sd, sd, d), 0.5 * r0, sd); // sqrt(d) with a correction step
-					colD[BUF][lane] = lane == K ? sd : (lane > K ? a[C] * r0 : 0.0);
-					if (lane == 0) rinv[BUF] = r0;
-				}
-				else
-					colB[BUF][lane] = a[C]; // raw entries of column K of the rows below; scaled by 1 / L_KK after the barrier
-			}
-			__syncthreads();
-			if (cg >= G) // waves whose columns are all left of K have nothing left to do
-			{
-				const double l = role == 0 ? colD[BUF][lane] : colB[BUF][lane] * rinv[BUF];
-				if (cg == G) a[C] = l;
-#pragma unroll
-				for (int jj = 0; jj < P16_COLS; ++jj)
-				{
-					// column index 16 cg + jj > K  <=>  cg > G, or cg == G and jj > C; the second case is resolved at compile time
-					if (jj > C) a[jj] = fma(-l, colD[BUF][cg * P16_COLS + jj], a[jj]);
-					else if (cg > G) a[jj] = fma(-l, colD[BUF][cg * P16_COLS + jj], a[jj]);
-				}
-			}
-		}
-		template <int... Ks>
-		__device__ __forceinline__ void panel16_columns(double (&a)[P16_COLS], double (*colD)[NB + 2], double (*colB)[NB], double* rinv, int lane, int role,
-			int cg, int& first_bad, std::integer_sequence<int, Ks...>)
-		{
-			(panel16_column<Ks>(a, colD, colB, rinv, lane, role, cg, first_bad), ...);
-		}
-		__global__ void __launch_bounds__(P16_THREADS) potrf_panel16_kernel(double* __restrict__ A, long lda, int m, int* __restrict__ info, int j0,
-			double* __restrict__ D, long ldd)
-		{
-			__shared__ __attribute__((aligned(16))) double colD[2][NB + 2];
-			__shared__ __attribute__((aligned(16))) double colB[2][NB];
-			__shared__ double rinv[2];
-			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-			const int role = w >> 2, cg = w & 3;
-			const int row = role == 0 ? lane : NB + blockIdx.x * NB + lane;
-			const bool valid = row < m;
-			double a[P16_COLS];
-			const double* __restrict__ src = A + (valid ? row : 0) + static_cast<long>(cg * P16_COLS) * lda;
-#pragma unroll
-			for (int j = 0; j < P16_COLS; ++j) a[j] = src[static_cast<long>(j) * lda];
-			int first_bad = 0;
-			panel16_columns(a, colD, colB, rinv, lane, role, cg, first_bad, std::make_integer_sequence<int, NB>{});
-			if (first_bad != 0 && lane == 0 && role == 0 && blockIdx.x == 0) atomicCAS(info, 0, j0 + first_bad); // info starts at 0
-			if (valid && (role == 1 || blockIdx.x == 0))
-			{
-				double* __restrict__ dst = (role == 0 ? D + row + static_cast<long>(cg * P16_COLS) * ldd : A + row + static_cast<long>(cg * P16_COLS) * lda);
-				const long ld = role == 0 ? ldd : lda;
-#pragma unroll
-				for (int j = 0; j < P16_COLS; ++j) dst[static_cast<long>(j) * ld] = a[j];
-			}
-		}
-
 		// ---- diagonal-block kernel: L_jj = chol(A_jj), T_jj = L_jj^-1 and the panel rows below, one launch ----------------------
-		// The panel sweep above spends ~320 ns per column (64 dependent steps of pivot -> 1/sqrt -> scale -> LDS publish ->
-		// barrier -> LDS read, with up to 63 FMAs per lane behind each), 20 us per panel, and it is the critical path of the fit.
+		// The panel step is the critical path of the fit.  Its first form (rounds 1-2: one sweep over the diagonal block and the rows
+		// below it, the scaled column published through LDS with a barrier per column) took ~320 ns per column, 20 us per panel.
 		// Here the 64 x 64 diagonal block is factored 16 columns at a time by ONE wave with a matrix row per lane and no LDS or
 		// barrier on the chain: every 16-lane DPP row also carries a replica of the 16 x 16 diagonal tile, so that the pivot and
 		// every multiplier L(base + j, k) is a row_newbcast of the replica — one v_fmac_f64_dpp per rank-1 entry instead of two
@@ -579,43 +351,6 @@ namespace gple
 			stamp();
 		}
 
-		// Tinv_b = L_b^-1 for every 64 x 64 diagonal block b of the factor (one wave per block, all blocks in one launch):
-		// lane j owns column j of the inverse and runs its own forward substitution; row r of L is an LDS broadcast.
-		// Called in place (L == T: the panel kernel leaves L_b in T's diagonal blocks): a block is read completely into LDS
-		// before the barrier and written after it, by its own workgroup only.
-		__global__ void __launch_bounds__(64) trinv_diag_kernel(const double* L, long ldl, double* T, long ldt)
-		{
-			__shared__ __attribute__((aligned(16))) double Ls[NB * LR];
-			const long off = static_cast<long>(blockIdx.x) * NB;
-			const double* Lb = L + off + off * ldl;
-			double* Tb = T + off + off * ldt;
-			const int i = threadIdx.x;
-#pragma unroll
-			for (int j = 0; j < NB; ++j)
-			{
-				const double v = Lb[i + static_cast<long>(j) * ldl];
-				Ls[i * LR + j] = (j == i) ? 1.0 / v : v; // the diagonal slot carries the reciprocal
-			}
-			__syncthreads();
-			// x[r] = (delta_rj - sum_{k<r} L(r,k) x[k]) / L(r,r); entries above the diagonal are 0, so every lane may start at k = 0
-			double x[NB];
-#pragma unroll
-			for (int r = 0; r < NB; ++r)
-			{
-				double s = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-				for (int k = 0; k < r; ++k) s = fma(-Ls[r * LR + k], x[k], s);
-				x[r] = (r >= i) ? s * Ls[r * LR + r] : 0.0;
-			}
-			__syncthreads();
-			// transpose through LDS for coalesced stores: Ls[c][r] <- X(r, c)
-#pragma unroll
-			for (int r = 0; r < NB; ++r) Ls[i * LR + r] = x[r];
-			__syncthreads();
-#pragma unroll
-			for (int c = 0; c < NB; ++c) Tb[i + static_cast<long>(c) * ldt] = Ls[c * LR + i];
-		}
-
 		// upper(i<j) = lower(j,i) for a full symmetric result
 		__global__ void __launch_bounds__(256) mirror_lower_kernel(double* __restrict__ W, long ldw, int n)
 		{
@@ -651,24 +386,6 @@ namespace gple
 		return n >= 2048 ? 256 : 0;
 	}
 
-	// 0: panel sweep (diagonal block re-factored per workgroup, rows below by substitution); 1: diagonal block factored and
-	// inverted by one workgroup (potrf_diag_kernel), rows below as the GEMM A21 T_jj^T
-	static int chol_scheme()
-	{
-		static const int v = [] {
-			const char* e = getenv("GPLE_CHOL_SCHEME");
-			return e ? atoi(e) : 1;
-		}();
-		return v;
-	}
-	static int panel_variant()
-	{
-		static const int v = [] {
-			const char* e = getenv("GPLE_PANEL_VARIANT");
-			return e ? atoi(e) : 0; // 1 = the column-split kernel: measured 23.6 us per panel against 20.5 (profiles/r02_notes.md)
-		}();
-		return v;
-	}
 	// panel steps of the block columns [j_begin, j_end) (multiples of NB; j_begin on an outer-block boundary or 0) of the n x n matrix
 	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end)
 	{
@@ -690,18 +407,13 @@ namespace gple
 			const int Jend = OB ? (J0 + OB < n ? J0 + OB : n) : n;
 			const int m = n - j0; // rows of the panel including the diagonal block
 			const int below = m - NB;
-			const int nwg = below > 0 ? (below + PANEL_ROWS - 1) / PANEL_ROWS : 1;
-			if (chol_scheme() == 1)
 			{
+				// diagonal block + the rows below it: one launch, one workgroup per 64 panel rows (each re-does the diagonal block)
 				double* Tjj = T + j0 + static_cast<long>(j0) * ldt;
 				const int ndt = below > 0 ? below / NB : 1;
 				hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(ndt), dim3(256), 0, s, at(j0, j0), lda, Tjj, ldt, info, j0, static_cast<long long*>(nullptr),
 					at(j0 + (below > 0 ? NB : 0), j0), below);
 			}
-			else if (panel_variant() == 1)
-				hipLaunchKernelGGL(potrf_panel16_kernel, dim3(nwg), dim3(P16_THREADS), 0, s, at(j0, j0), lda, m, info, j0, T + j0 + static_cast<long>(j0) * ldt, ldt);
-			else
-				hipLaunchKernelGGL(potrf_panel_kernel, dim3(nwg), dim3(PANEL_THREADS), 0, s, at(j0, j0), lda, m, info, j0, T + j0 + static_cast<long>(j0) * ldt, ldt);
 			// the rest of this block column: rows j0 + NB .. n, columns j0 + NB .. Jend
 			if (Jend - (j0 + NB) > 0)
 			{
@@ -730,8 +442,6 @@ namespace gple
 		if (n % NB) return hipErrorInvalidValue;
 		const hipError_t e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n);
 		if (e != hipSuccess) return e;
-		// the 64 x 64 inverses are only the leaves of the merge tree: one batched launch, off the factorisation's critical path
-		if (chol_scheme() != 1) hipLaunchKernelGGL(trinv_diag_kernel, dim3(n / NB), dim3(64), 0, s, T, ldt, T, ldt);
 		return hipGetLastError();
 	}
 
@@ -838,7 +548,6 @@ namespace gple
 		if ((e = hipEventRecord(ctx->side_fork, s)) != hipSuccess) return e;
 		// side stream: T11 = L11^-1 and W = L21 T11, all inputs final
 		if ((e = hipStreamWaitEvent(side, ctx->side_fork, 0)) != hipSuccess) return e;
-		if (chol_scheme() != 1) hipLaunchKernelGGL(trinv_diag_kernel, dim3(H / NB), dim3(64), 0, side, T, ldt, T, ldt);
 		if ((e = trtri_lower_from_diag(side, A, lda, T, ldt, H, w_lead)) != hipSuccess) return e;
 		{
 			GemmDesc g{};
@@ -851,7 +560,6 @@ namespace gple
 		// main stream meanwhile: trailing block columns and their inverse
 		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, H, n)) != hipSuccess) return e;
 		double* T22 = T + H + static_cast<long>(H) * ldt;
-		if (chol_scheme() != 1) hipLaunchKernelGGL(trinv_diag_kernel, dim3((n - H) / NB), dim3(64), 0, s, T22, ldt, T22, ldt);
 		if ((e = trtri_lower_from_diag(s, A + H + static_cast<long>(H) * lda, lda, T22, ldt, n - H, w_trail)) != hipSuccess) return e;
 		// join: T21 = -T22 W
 		if ((e = hipStreamWaitEvent(s, ctx->side_join, 0)) != hipSuccess) return e;

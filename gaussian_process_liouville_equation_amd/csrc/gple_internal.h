@@ -139,9 +139,10 @@ namespace gple
 
 	// ---- dense factorisation drivers (gple_chol.hip) -------------------------------------------------------
 	// Lower Cholesky of the n x n (n multiple of CHOL_NB) column-major matrix A: the blocks strictly below the block
-	// diagonal are overwritten by the factor; the CHOL_NB diagonal blocks of A are left untouched (their factors pass through
-	// T's diagonal blocks, see potrf_panel_kernel) and the upper part is not referenced.  On return T (n x n, ldt) holds
-	// inv(L_jj) in every diagonal block, i.e. the diagonal blocks of T = L^-1.  info (device int): 0 or 1 + index of the
+	// diagonal are overwritten by the factor; the CHOL_NB diagonal blocks of A keep their (updated, unfactored) contents — every
+	// workgroup of a panel step reads its diagonal block, none may overwrite it — and the upper part is not referenced.  The
+	// diagonal blocks of the factor are never stored: on return T (n x n, ldt) holds inv(L_jj) in every diagonal block (full
+	// 64 x 64 blocks, zeros above the diagonal), i.e. the diagonal blocks of T = L^-1 (potrf_diag_kernel).  info (device int): 0 or 1 + index of the
 	// first non-positive pivot.
 	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info);
 	hipError_t debug_potrf_diag(hipStream_t s, const double* A, double* T, int* info, long long* stamps);
