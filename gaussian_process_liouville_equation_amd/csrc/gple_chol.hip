@@ -121,7 +121,9 @@ namespace gple
 			const double* const qrow = S + (base + (lane & 15)) * DLS + base;
 #pragma unroll
 			for (int k = 0; k < 16; ++k) p[k] = prow[k], q[k] = qrow[k];
-			double lq = 0.0, nlq = 0.0, nl = 0.0;
+			// the broadcast carries -L(base + j, k); the per-lane factor is the lane's own multiplier (l for p, lq for q)
+			double nlq = 0.0, lq = 0.0, l = 0.0;
+			constexpr bool ROWS_BELOW = SP < 3; // the last sub-panel is its diagonal tile only: p == q in the one DPP row that counts
 			[&]<int... Ks>(std::integer_sequence<int, Ks...>)
 			{
 				(
@@ -134,25 +136,27 @@ namespace gple
 						if constexpr (k > 0)
 							[&]<int... Js>(std::integer_sequence<int, Js...>)
 							{
-								((Js > k ? (dpp_fmac<Js>(q[Js], lq, nlq), dpp_fmac<Js>(p[Js], lq, nl)) : (void)0), ...);
+								((Js > k ? (dpp_fmac<Js>(q[Js], nlq, lq), (ROWS_BELOW ? dpp_fmac<Js>(p[Js], nlq, l) : (void)0)) : (void)0), ...);
 							}
 							(std::make_integer_sequence<int, 16>{});
-						const double nr = -r;
-						lq = dpp_mul(q[k], r);
-						nlq = q[k] * nr;
-						p[k] = p[k] * r;
-						nl = -p[k];
+						nlq = dpp_mul(q[k], -r);
+						lq = q[k] * r;
+						if constexpr (ROWS_BELOW) l = p[k] * r, p[k] = l;
+						else q[k] = lq;
 						dpp_fence();
 						if constexpr (k + 1 < 16)
 						{
-							dpp_fmac<k + 1>(q[k + 1], lq, nlq);
-							dpp_fmac<k + 1>(p[k + 1], lq, nl);
+							dpp_fmac<k + 1>(q[k + 1], nlq, lq);
+							if constexpr (ROWS_BELOW) dpp_fmac<k + 1>(p[k + 1], nlq, l);
 						}
 						__builtin_amdgcn_sched_barrier(0);
 					}(),
 					...);
 			}
 			(std::make_integer_sequence<int, 16>{});
+			if constexpr (!ROWS_BELOW)
+#pragma unroll
+				for (int k = 0; k < 16; ++k) p[k] = q[k]; // lanes 0..15 hold rows 48..63 either way
 			if (base + lane < NB)
 #pragma unroll
 				for (int k = 0; k < 16; ++k) prow[k] = p[k];
