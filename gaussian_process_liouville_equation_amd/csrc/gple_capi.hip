@@ -307,9 +307,8 @@ namespace
 		timer_start(ctx, GPLE_TIMER_FIT);
 		const size_t ylen = N * static_cast<size_t>(y_stride);
 		GPLE_HIP(ctx, ytmp.get(ylen));
-		GPLE_HIP(ctx, Lbuf.get(static_cast<size_t>(nt) * nt));
+		GPLE_HIP(ctx, Lbuf.get(static_cast<size_t>(nt + CHOL_NB) * nt));
 		GPLE_HIP(ctx, work.get(chol_inverse_work_doubles(nt)));
-		GPLE_HIP(ctx, part.get(static_cast<size_t>(nt / 256) * nt));
 		GPLE_HIP(ctx, u.get(nt));
 
 		// device inputs are read in place; host inputs are staged by two copies.  One launch then pads the points, clears the
@@ -325,10 +324,11 @@ namespace
 		}
 		GPLE_HIP(ctx, launch_prep_labels(st, yin, y_stride, f->is_complex ? 1 : 0, f->N, Np, f->ys, f->sdev, Xin, f->Xt, SDEV_N));
 		GPLE_HIP(ctx, hipMemsetAsync(f->T, 0, static_cast<size_t>(nt) * nt * 8, st));
-		GPLE_HIP(ctx, launch_gram_train(st, f->Xt, f->N, Np, nt, f->ps, Lbuf.p, nt));
+		// the scaled labels ride below the matrix as one more block row: its factor is u = L^-1 ys (= T ys, without the two launches)
+		const long ldl = nt + CHOL_NB;
+		GPLE_HIP(ctx, launch_gram_train(st, f->Xt, f->N, Np, nt, f->ps, Lbuf.p, ldl, f->ys));
 		int* info_dev = reinterpret_cast<int*>(f->sdev + 31);
-		GPLE_HIP(ctx, chol_inverse_factor(ctx, st, Lbuf.p, nt, nt, f->T, nt, info_dev, work.p));
-		GPLE_HIP(ctx, launch_trmv_lower(st, f->T, nt, nt, f->ys, part.p, u.p));
+		GPLE_HIP(ctx, chol_inverse_factor(ctx, st, Lbuf.p, ldl, nt, f->T, nt, info_dev, work.p, u.p));
 		GPLE_HIP(ctx, launch_colpass(st, f->T, nt, nt, u.p, f->v, f->w, Np, f->wx));
 		return GPLE_OK;
 	}

@@ -212,7 +212,7 @@ namespace gple
 		// requested from HBM before the factorisation starts.  Workgroup 0 also stores T_jj.
 		template <bool PROBE>
 		__global__ void __launch_bounds__(256) potrf_diag_kernel(const double* __restrict__ A, long lda, double* __restrict__ T, long ldt, int* __restrict__ info,
-			int j0, long long* __restrict__ stamps, double* __restrict__ P, int below)
+			int j0, long long* __restrict__ stamps, double* __restrict__ P, int below, double* __restrict__ uvec)
 		{
 			int stamp_i = 0;
 			auto stamp = [&]() {
@@ -351,6 +351,8 @@ namespace gple
 					const int c = (t >> 6) + 4 * q;
 					Pb[r + static_cast<long>(c) * lda] = S[r * DLS + c];
 				}
+				// the label row carried below the matrix (chol_inverse_factor, `uvec`): its factor entries are u = L^-1 y, 64 per panel
+				if (uvec != nullptr && blockIdx.x == gridDim.x - 1 && t < NB) uvec[j0 + t] = S[t];
 			}
 			stamp();
 		}
@@ -391,7 +393,9 @@ namespace gple
 	}
 
 	// panel steps of the block columns [j_begin, j_end) (multiples of NB; j_begin on an outer-block boundary or 0) of the n x n matrix
-	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end)
+	// uvec != nullptr: A carries one more block row (rows n .. n + NB - 1, row n = the scaled labels y, the rest zero); it is factored
+	// along as part of every panel, which leaves u = L^-1 y in its first row — collected into uvec — at no extra launch
+	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end, double* uvec)
 	{
 		const int OB = chol_outer_block(n);
 		auto at = [&](int r, int c) { return A + r + static_cast<long>(c) * lda; };
@@ -409,14 +413,15 @@ namespace gple
 		{
 			const int J0 = OB ? j0 / OB * OB : 0;                      // outer block column of this panel
 			const int Jend = OB ? (J0 + OB < n ? J0 + OB : n) : n;
-			const int m = n - j0; // rows of the panel including the diagonal block
+			const int extra = uvec ? NB : 0;
+			const int m = n + extra - j0; // rows of the panel including the diagonal block
 			const int below = m - NB;
 			{
 				// diagonal block + the rows below it: one launch, one workgroup per 64 panel rows (each re-does the diagonal block)
 				double* Tjj = T + j0 + static_cast<long>(j0) * ldt;
 				const int ndt = below > 0 ? below / NB : 1;
 				hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(ndt), dim3(256), 0, s, at(j0, j0), lda, Tjj, ldt, info, j0, static_cast<long long*>(nullptr),
-					at(j0 + (below > 0 ? NB : 0), j0), below);
+					at(j0 + (below > 0 ? NB : 0), j0), below, uvec);
 			}
 			// the rest of this block column: rows j0 + NB .. n, columns j0 + NB .. Jend
 			if (Jend - (j0 + NB) > 0)
@@ -427,7 +432,7 @@ namespace gple
 			// last panel of an outer block: everything right of the block column, once, with K = the block's width
 			if (j0 + NB == Jend && n - Jend > 0)
 			{
-				const hipError_t e = syrk_update(Jend, n - Jend, n - Jend, J0, Jend - J0);
+				const hipError_t e = syrk_update(Jend, n + extra - Jend, n - Jend, J0, Jend - J0);
 				if (e != hipSuccess) return e;
 			}
 		}
@@ -437,14 +442,14 @@ namespace gple
 	// probe entry (probes/diag_probe.py): one instrumented launch of the diagonal-block kernel on device buffers
 	hipError_t debug_potrf_diag(hipStream_t s, const double* A, double* T, int* info, long long* stamps)
 	{
-		hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), 0, s, A, 64L, T, 64L, info, 0, stamps, const_cast<double*>(A), 0);
+		hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), 0, s, A, 64L, T, 64L, info, 0, stamps, const_cast<double*>(A), 0, static_cast<double*>(nullptr));
 		return hipGetLastError();
 	}
 
-	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info)
+	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec)
 	{
 		if (n % NB) return hipErrorInvalidValue;
-		const hipError_t e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n);
+		const hipError_t e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n, uvec);
 		if (e != hipSuccess) return e;
 		return hipGetLastError();
 	}
@@ -524,13 +529,13 @@ namespace gple
 		const size_t H = static_cast<size_t>(chol_split_point(n)), R = static_cast<size_t>(n) - H;
 		return R * H + H * H / 4 + R * R / 4 + static_cast<size_t>(n) * static_cast<size_t>(n) / 4 + 64; // last term: the unsplit path
 	}
-	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work)
+	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work, double* uvec)
 	{
 		if (n % NB) return hipErrorInvalidValue;
 		const int nblocks = n / NB;
 		if (n < chol_overlap_min_n() || nblocks < 4)
 		{
-			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info);
+			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info, uvec);
 			if (e != hipSuccess) return e;
 			return trtri_lower_from_diag(s, A, lda, T, ldt, n, work);
 		}
@@ -548,7 +553,7 @@ namespace gple
 		double* w_lead = w_top + Rs * Hs;          // tree of the leading half
 		double* w_trail = w_lead + Hs * Hs / 4;    // tree of the trailing half
 		// main stream: leading block columns
-		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, H)) != hipSuccess) return e;
+		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, H, uvec)) != hipSuccess) return e;
 		if ((e = hipEventRecord(ctx->side_fork, s)) != hipSuccess) return e;
 		// side stream: T11 = L11^-1 and W = L21 T11, all inputs final
 		if ((e = hipStreamWaitEvent(side, ctx->side_fork, 0)) != hipSuccess) return e;
@@ -562,7 +567,7 @@ namespace gple
 		}
 		if ((e = hipEventRecord(ctx->side_join, side)) != hipSuccess) return e;
 		// main stream meanwhile: trailing block columns and their inverse
-		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, H, n)) != hipSuccess) return e;
+		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, H, n, uvec)) != hipSuccess) return e;
 		double* T22 = T + H + static_cast<long>(H) * ldt;
 		if ((e = trtri_lower_from_diag(s, A + H + static_cast<long>(H) * lda, lda, T22, ldt, n - H, w_trail)) != hipSuccess) return e;
 		// join: T21 = -T22 W

@@ -144,7 +144,7 @@ namespace gple
 	// diagonal blocks of the factor are never stored: on return T (n x n, ldt) holds inv(L_jj) in every diagonal block (full
 	// 64 x 64 blocks, zeros above the diagonal), i.e. the diagonal blocks of T = L^-1 (potrf_diag_kernel).  info (device int): 0 or 1 + index of the
 	// first non-positive pivot.
-	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info);
+	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec = nullptr);
 	hipError_t debug_potrf_diag(hipStream_t s, const double* A, double* T, int* info, long long* stamps);
 	// Completes T = L^-1 (lower) given its diagonal blocks; work: at least n*n/4 doubles.
 	hipError_t trtri_lower_from_diag(hipStream_t s, const double* L, long ldl, double* T, long ldt, int n, double* work);
@@ -152,7 +152,10 @@ namespace gple
 	// leading half (its merge tree and the first GEMM of the last merge, more than half of the tree's work) running on the
 	// context's side stream while the main stream factors the trailing half.  work: chol_inverse_work_doubles(n) doubles.
 	size_t chol_inverse_work_doubles(int n);
-	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work);
+	// uvec != nullptr: A has n + CHOL_NB rows (lda >= n + CHOL_NB), row n holds a right-hand side y and the rows below it zeros;
+	// the extra block row is factored along and uvec receives u = L^-1 y (what a fit otherwise computes as T y in two more launches).
+	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work,
+		double* uvec = nullptr);
 	// W = T^T T (full symmetric n x n).
 	hipError_t lauum_full(hipStream_t s, const double* T, long ldt, double* W, long ldw, int n);
 } // namespace gple

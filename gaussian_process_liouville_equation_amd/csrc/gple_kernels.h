@@ -28,7 +28,9 @@ namespace gple
 		const double* X, double* Xt, int nscal);
 	// K_pad (n_total x n_total, ld) of the typed training set: n_total = Np (real) or 2*Np (complex, split at Np);
 	// points Xt (N interleaved); padded rows/cols get the identity.
-	hipError_t launch_gram_train(hipStream_t s, const double* Xt, int N, int Np, int n_total, SEParamSet ps, double* K, long ld);
+	// ys != nullptr: K has n_total + 64 rows; row n_total receives ys (length n_total), the 63 rows below it zeros
+	hipError_t launch_gram_train(hipStream_t s, const double* Xt, int N, int Np, int n_total, SEParamSet ps, double* K, long ld,
+		const double* ys = nullptr);
 	// u = T * ys (lower triangular T, n x n): partial sums then reduction. part: (n/256) * n doubles.
 	hipError_t launch_trmv_lower(hipStream_t s, const double* T, long ldt, int n, const double* ys, double* part, double* u);
 	// v[k] = sum_i T(i,k) u[i],  w[k] = sum_i T(i,k)^2 ; optionally wx[k] = sum_i T(i,k) T(i,k+shift) (complex: diag of Mxy).

@@ -92,10 +92,21 @@ namespace gple
 		}
 
 		// typed training Gram, padded with the identity
+		// blockIdx.x == n_total / 64 (launched only when ys != nullptr): the label row below the matrix, row n_total = ys, then zeros
 		__global__ void __launch_bounds__(256) gram_train_kernel(const double* __restrict__ Xt, int N, int Np, int n_total, SEParamSet ps,
-			double* __restrict__ K, long ld)
+			double* __restrict__ K, long ld, const double* __restrict__ ys)
 		{
 			const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+			if (i >= n_total)
+			{
+#pragma unroll
+				for (int e = 0; e < 4; ++e)
+				{
+					const int j = blockIdx.y * 16 + (threadIdx.x >> 6) * 4 + e;
+					K[i + static_cast<long>(j) * ld] = i == n_total ? ys[j] : 0.0;
+				}
+				return;
+			}
 			const int ti = i >= Np, pi = ti ? i - Np : i;
 			const bool vi = pi < N;
 			double xi0 = 0.0, xi1 = 0.0;
@@ -362,9 +373,9 @@ namespace gple
 		hipLaunchKernelGGL(prep_labels_kernel, dim3(1), dim3(1024), 0, s, y, stride, complex_abs, N, Np, ys, s_out, X, Xt, nscal);
 		return hipGetLastError();
 	}
-	hipError_t launch_gram_train(hipStream_t s, const double* Xt, int N, int Np, int n_total, SEParamSet ps, double* K, long ld)
+	hipError_t launch_gram_train(hipStream_t s, const double* Xt, int N, int Np, int n_total, SEParamSet ps, double* K, long ld, const double* ys)
 	{
-		hipLaunchKernelGGL(gram_train_kernel, dim3(n_total / 64, n_total / 16), dim3(256), 0, s, Xt, N, Np, n_total, ps, K, ld);
+		hipLaunchKernelGGL(gram_train_kernel, dim3(n_total / 64 + (ys ? 1 : 0), n_total / 16), dim3(256), 0, s, Xt, N, Np, n_total, ps, K, ld, ys);
 		return hipGetLastError();
 	}
 	hipError_t launch_trmv_lower(hipStream_t s, const double* T, long ldt, int n, const double* ys, double* part, double* u)
