@@ -931,14 +931,17 @@ extern "C"
 		int status = fit_common(ctx, f, X, y, y_is_complex ? 2 : 1, N, flags);
 		if (status == GPLE_OK)
 		{
-			hipError_t e = launch_real_fit_sums(st, f->Xt, f->ys, f->v, f->w, f->N, f->sdev + 1);
-			if (e == hipSuccess && (flags & GPLE_CALC_AVERAGE))
+			hipError_t e = hipSuccess;
+			Scratch part(ctx);
+			const size_t g = (N + 63) / 64;
+			const bool avg = (flags & GPLE_CALC_AVERAGE) != 0;
+			if (avg) // purity: v^T K1 v; its per-block partials are summed by the same launch that forms the other sums
 			{
-				Scratch part(ctx);
-				const size_t g = (N + 63) / 64;
 				e = part.get(g * g);
-				if (e == hipSuccess) e = launch_quadform(st, f->Xt, f->N, purity_aux(sf, l0, l1), f->v, f->v, -1, part.p, f->sdev + 6);
+				if (e == hipSuccess) e = launch_quadform_partials(st, f->Xt, f->N, purity_aux(sf, l0, l1), f->v, f->v, -1, part.p);
 			}
+			if (e == hipSuccess)
+				e = launch_real_fit_sums(st, f->Xt, f->ys, f->v, f->w, f->N, f->sdev + 1, avg ? part.p : nullptr, static_cast<int>(g * g), f->sdev + 6);
 			if (e == hipSuccess && (flags & GPLE_CALC_DERIVATIVE))
 			{
 				status = real_fit_derivatives(ctx, f, sf, l0, l1, sn, flags);

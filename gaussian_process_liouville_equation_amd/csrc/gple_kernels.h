@@ -37,8 +37,11 @@ namespace gple
 	hipError_t launch_colpass(hipStream_t s, const double* T, long ldt, int n, const double* u, double* v, double* w, int shift,
 		double* wx);
 	// raw sums for the real fit: out[0]=sum (v/w)^2, out[1]=sum v, out[2]=sum x v, out[3]=sum p v, out[4]=sum ys v
-	hipError_t launch_real_fit_sums(hipStream_t s, const double* Xt, const double* ys, const double* v, const double* w, int N,
-		double* out);
+	// out[0..4]: the five sums of a real fit; qpart != nullptr: also *qout = sum of the nq per-block partials of a quadratic form
+	// (launch_quadform_partials), saving the separate reduction launch
+	hipError_t launch_real_fit_sums(hipStream_t s, const double* Xt, const double* ys, const double* v, const double* w, int N, double* out,
+		const double* qpart = nullptr, int nq = 0, double* qout = nullptr);
+	hipError_t launch_quadform_partials(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, int fdim, double* part);
 	// out[0] = sum_ij a_i k(x_i,x_j) b_j over i,j < N with the bit-faithful SE kernel p (amp folded in, no noise)
 	// fdim >= 0 multiplies every entry by ((x_i,d - x_j,d)/l_d)^2 / l_d: the kernel's derivative over l_d (kernel.cpp:99-160)
 	hipError_t launch_quadform(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, int fdim, double* part,

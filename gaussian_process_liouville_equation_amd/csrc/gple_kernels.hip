@@ -180,11 +180,13 @@ namespace gple
 			}
 		}
 
+		// qpart != nullptr: also the final sum of the purity quadratic form's per-block partials (quadform_kernel) -> qout
 		__global__ void __launch_bounds__(1024) real_fit_sums_kernel(const double* __restrict__ Xt, const double* __restrict__ ys,
-			const double* __restrict__ v, const double* __restrict__ w, int N, double* __restrict__ out)
+			const double* __restrict__ v, const double* __restrict__ w, int N, double* __restrict__ out, const double* __restrict__ qpart, int nq,
+			double* __restrict__ qout)
 		{
 			__shared__ double red[16];
-			double s[5] = {0, 0, 0, 0, 0};
+			double s[6] = {0, 0, 0, 0, 0, 0};
 			for (int i = threadIdx.x; i < N; i += 1024)
 			{
 				const double vi = v[i], r = vi / w[i];
@@ -194,10 +196,17 @@ namespace gple
 				s[3] += Xt[2 * i + 1] * vi;
 				s[4] += ys[i] * vi; // Label.dot(InvLbl), kernel.h:169
 			}
+			if (qpart != nullptr)
+				for (int i = threadIdx.x; i < nq; i += 1024) s[5] += qpart[i]; // same order of additions as sum_kernel
 			for (int q = 0; q < 5; ++q)
 			{
 				const double tot = block_sum<1024>(s[q], red);
 				if (threadIdx.x == 0) out[q] = tot;
+			}
+			if (qpart != nullptr)
+			{
+				const double tot = block_sum<1024>(s[5], red);
+				if (threadIdx.x == 0) *qout = tot;
 			}
 		}
 
@@ -389,9 +398,16 @@ namespace gple
 		hipLaunchKernelGGL(colpass_kernel, dim3(n / 4), dim3(256), 0, s, T, ldt, n, u, v, w, shift, wx);
 		return hipGetLastError();
 	}
-	hipError_t launch_real_fit_sums(hipStream_t s, const double* Xt, const double* ys, const double* v, const double* w, int N, double* out)
+	hipError_t launch_real_fit_sums(hipStream_t s, const double* Xt, const double* ys, const double* v, const double* w, int N, double* out,
+		const double* qpart, int nq, double* qout)
 	{
-		hipLaunchKernelGGL(real_fit_sums_kernel, dim3(1), dim3(1024), 0, s, Xt, ys, v, w, N, out);
+		hipLaunchKernelGGL(real_fit_sums_kernel, dim3(1), dim3(1024), 0, s, Xt, ys, v, w, N, out, qpart, nq, qout);
+		return hipGetLastError();
+	}
+	hipError_t launch_quadform_partials(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, int fdim, double* part)
+	{
+		const int g = (N + 63) / 64;
+		hipLaunchKernelGGL(quadform_kernel, dim3(g, g), dim3(256), 0, s, Xt, N, p, a, b, fdim, part);
 		return hipGetLastError();
 	}
 	hipError_t launch_quadform(hipStream_t s, const double* Xt, int N, SEParam p, const double* a, const double* b, int fdim, double* part,
