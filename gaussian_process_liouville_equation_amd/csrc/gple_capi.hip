@@ -2029,4 +2029,34 @@ extern "C"
 		GPLE_HIP(ctx, hipMemcpy(stamps, aux.p + 8, 16 * 8, hipMemcpyDeviceToHost));
 		return GPLE_OK;
 	}
+
+	/* not part of include/gple.h: one product of the fp64 MFMA GEMM family on host operands, for tests/test_gpu_gemm.py.
+	 * C(m,n) = alpha sum_k A(m,k) B(n,k) + beta C(m,n); layouts and k-ranges as GemmDesc (csrc/gple_internal.h);
+	 * tile = 32 | 64 | 128 | 0 (the library's own choice for this shape). */
+	int gple_debug_gemm(gple_ctx* ctx, const double* A, long lda, int a_kmajor, const double* B, long ldb, int b_kmajor, double* C, long ldc,
+		int c_trans, int M, int N, int K, double alpha, double beta, int krange, int lower_only, int tile)
+	{
+		if (!ctx || !A || !B || !C || M <= 0 || N <= 0 || K <= 0) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		const size_t na = static_cast<size_t>(lda) * (a_kmajor ? M : K), nb = static_cast<size_t>(ldb) * (b_kmajor ? N : K),
+					 nc = static_cast<size_t>(ldc) * (c_trans ? M : N);
+		Scratch a(ctx), b(ctx), c(ctx);
+		GPLE_HIP(ctx, a.get(na));
+		GPLE_HIP(ctx, b.get(nb));
+		GPLE_HIP(ctx, c.get(nc));
+		GPLE_HIP(ctx, copy_in(st, a.p, A, na, false));
+		GPLE_HIP(ctx, copy_in(st, b.p, B, nb, false));
+		GPLE_HIP(ctx, copy_in(st, c.p, C, nc, false));
+		GemmDesc g{};
+		g.A = a.p, g.lda = lda, g.B = b.p, g.ldb = ldb, g.C = c.p, g.ldc = ldc;
+		g.M = M, g.N = N, g.K = K, g.batch = 1, g.alpha = alpha, g.beta = beta, g.krange = krange, g.lower_only = lower_only;
+		g.a_kmajor = a_kmajor != 0, g.b_kmajor = b_kmajor != 0, g.c_trans = c_trans != 0;
+		GPLE_HIP(ctx, launch_gemm(st, g, tile ? tile : gemm_pick_tile(M, N, 1, krange != K_FULL || lower_only)));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		GPLE_HIP(ctx, hipMemcpy(C, c.p, nc * 8, hipMemcpyDeviceToHost));
+		return GPLE_OK;
+	}
 }
