@@ -10,8 +10,11 @@
 // workspace and all predict scratch belong to the context's buffer pool and are reused across calls.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -233,6 +236,19 @@ struct FitCommon
 	double self = 0.0; // k(x*, x*)
 	FitCommon() { std::memset(dspec, 0, sizeof(dspec)); }
 	std::mutex lazy_mu;
+	// one-point predicts from several host threads on this fit (the reference calls its DistributionFunction from TBB workers,
+	// evolve.cpp:392-420, mc.cpp:214-246): requests that arrive while a predict is in flight are served together by the next one
+	struct PointRequest
+	{
+		const double* x;
+		double *mean, *var, *cut;
+		int status;
+		bool done;
+	};
+	mutable std::mutex point_mu;
+	mutable std::condition_variable point_cv;
+	mutable std::vector<PointRequest*> point_pending;
+	mutable bool point_leader = false;
 
 	~FitCommon()
 	{
@@ -1196,11 +1212,77 @@ extern "C"
 		return GPLE_OK;
 	}
 
+	// One-point predict with host pointers and no labels — what main.cpp:83,94 issues per call, from as many threads as TBB has.
+	// The calls on one context are serialised anyway (one stream); instead of queueing behind each other, the requests that
+	// pile up while a predict is in flight ride together on the next one (up to 16 typed rows: the few-points path costs the
+	// same for 16 points as for one).  Every caller still returns with its own result; a single-threaded caller sees a batch of one.
+	static int predict_point_combined(gple_ctx* ctx, const FitCommon* f, const double* x, double* prediction, double* variance,
+		double* cutoff_prediction)
+	{
+		const size_t ow = f->is_complex ? 2 : 1, cap = FEW_HOST_POINTS / ow;
+		FitCommon::PointRequest r{x, prediction, variance, cutoff_prediction, GPLE_OK, false};
+		std::unique_lock<std::mutex> lk(f->point_mu);
+		f->point_pending.push_back(&r);
+		for (;;)
+		{
+			if (r.done) return r.status;
+			if (f->point_leader)
+			{
+				f->point_cv.wait(lk);
+				continue;
+			}
+			f->point_leader = true; // serve the oldest requests (this thread's own is among the pending ones; FIFO gets to it)
+			const size_t nb = std::min(cap, f->point_pending.size());
+			FitCommon::PointRequest* batch[FEW_HOST_POINTS];
+			double xs[2 * FEW_HOST_POINTS], mean[2 * FEW_HOST_POINTS], var[FEW_HOST_POINTS], cut[2 * FEW_HOST_POINTS];
+			for (size_t i = 0; i < nb; ++i)
+			{
+				batch[i] = f->point_pending[i];
+				xs[2 * i] = batch[i]->x[0], xs[2 * i + 1] = batch[i]->x[1];
+			}
+			f->point_pending.erase(f->point_pending.begin(), f->point_pending.begin() + static_cast<long>(nb));
+			lk.unlock();
+			const int st = predict_common(ctx, f, xs, nb, 0u, nullptr, mean, var, cut, nullptr);
+			lk.lock();
+			for (size_t i = 0; i < nb; ++i)
+			{
+				FitCommon::PointRequest* q = batch[i];
+				if (st == GPLE_OK)
+				{
+					if (q->mean) std::memcpy(q->mean, mean + ow * i, ow * sizeof(double));
+					if (q->var) *q->var = var[i];
+					if (q->cut) std::memcpy(q->cut, cut + ow * i, ow * sizeof(double));
+				}
+				q->status = st;
+				q->done = true;
+			}
+			f->point_leader = false;
+			f->point_cv.notify_all();
+		}
+	}
+	static bool point_combining()
+	{
+		static const bool on = [] {
+			const char* e = getenv("GPLE_POINT_COMBINE");
+			return !e || atoi(e) != 0;
+		}();
+		return on;
+	}
+
 	int gple_real_predict(gple_ctx* ctx, const gple_real_fit* fit, const double* Xs, size_t M, unsigned flags, const double* labels,
 		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars)
 	{
 		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
+		if (M == 1 && !labels && !(flags & GPLE_IO_DEVICE) && point_combining())
+		{
+			if (scalars)
+			{
+				scalars->error = nan_();
+				for (double& d : scalars->error_derivative) d = nan_();
+			}
+			return predict_point_combined(ctx, fit, Xs, prediction, variance, cutoff_prediction);
+		}
 		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
 	}
 
@@ -1427,6 +1509,15 @@ extern "C"
 	{
 		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
+		if (M == 1 && !labels && !(flags & GPLE_IO_DEVICE) && point_combining())
+		{
+			if (scalars)
+			{
+				scalars->error = nan_();
+				for (double& d : scalars->error_derivative) d = nan_();
+			}
+			return predict_point_combined(ctx, fit, Xs, prediction, variance, cutoff_prediction);
+		}
 		return predict_common(ctx, fit, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars);
 	}
 

@@ -15,8 +15,10 @@
 #include "predict.h"
 #include "storage.h"
 
+#include <chrono>
 #include <cstdio>
 #include <sstream>
+#include <thread>
 
 using Bounds = std::array<ParameterVector, 2>;
 using ElementTrainingParameters = std::tuple<const ElementTrainingSet&, const ElementTrainingSet&>;                                      // opt.cpp:16
@@ -203,6 +205,32 @@ int main(int argc, char** argv)
 	std::printf("mean_r %.17g %.17g\npopulation_0 %.17g\n", mean_r[0], mean_r[1], calculate_population_one_surface((*all_kernels)(0).value()));
 	// output.cpp:262-290
 	std::printf("rescale %.17g %.17g\n", (*all_kernels)(0)->get_rescale_factor(), (*all_kernels)(1, 0)->get_rescale_factor());
+
+	// evolve.cpp:392-420, mc.cpp:214-246: the same lambda from several worker threads at once (std::thread standing in for TBB);
+	// every thread must get what the lone call returns, and the calls per second are printed for one and for eight threads
+	{
+		const std::size_t per_thread = 400;
+		auto run = [&](std::size_t nthreads) -> std::pair<double, bool>
+		{
+			std::vector<std::thread> workers;
+			std::vector<char> ok(nthreads, 1);
+			const auto t0 = std::chrono::steady_clock::now();
+			for (std::size_t w = 0; w < nthreads; w++)
+				workers.emplace_back([&, w]() {
+					for (std::size_t i = 0; i < per_thread; i++)
+					{
+						const std::complex<double> a = predict_distribution(r0, 0, 0), b = predict_distribution(r0, 1, 0);
+						if (a != d00 || b != d10) ok[w] = 0;
+					}
+				});
+			for (std::thread& t : workers) t.join();
+			const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			return {2.0 * per_thread * nthreads / dt, std::all_of(ok.begin(), ok.end(), [](char c) { return c != 0; })};
+		};
+		const auto [rate1, ok1] = run(1);
+		const auto [rate8, ok8] = run(8);
+		std::printf("threads_rate %.1f %.1f\nthreads_same %d %d\n", rate1, rate8, ok1 ? 1 : 0, ok8 ? 1 : 0);
+	}
 
 	// the batched replacement (N1): same values as the point-wise lambda
 	gple_host::DistributionBatcher batcher(*all_kernels);

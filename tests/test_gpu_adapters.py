@@ -67,6 +67,9 @@ def test_reference_call_patterns_through_the_adapters(gpu, oracle):
         assert close(got[k], [p10.real, p10.imag], 1e-6), k
     assert np.all(got["point_last"] == 0) and np.all(got["batch_last"] == 0)  # element without a kernel (main.cpp:86-88)
     assert np.array_equal(got["point_00"], got["batch_00"]) and np.array_equal(got["point_10"], got["batch_10"])
+    # the point-wise lambda from eight threads at once: same values, and not slower than one thread (requests ride together)
+    assert np.all(got["threads_same"] == 1)
+    assert got["threads_rate"][1] >= 0.8 * got["threads_rate"][0], got["threads_rate"]
     assert close(got["all_population"], ko.calculate_population()) and close(got["all_purity"], ko.calculate_purity(), 1e-6)
     assert close(got["all_energy"], ko.calculate_total_energy_average([0.1, 0.2]))
     assert close(got["mean_r"], ko(0).get_1st_order_average() / ko(0).get_population())

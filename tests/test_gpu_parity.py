@@ -437,3 +437,36 @@ def test_few_points_predict_path(gpu, oracle, monkeypatch):
     e_few = gpu.real_predict(fr, X[:4], labels=lab)["error"]
     e_ref = oracle.real_predict(fro, X[:4], labels=lab)["error"]
     assert abs(e_few - e_ref) <= 1e-7 * max(abs(e_ref), 1e-12) + 1e-12
+
+
+def test_one_point_predicts_from_many_threads(gpu):
+    """§8(b) threading: one-point predicts on a shared fit from several host threads (evolve.cpp:392-420 calls the
+    DistributionFunction from TBB workers).  Requests that pile up behind a predict in flight are served together by the next
+    one (gple_capi.hip, predict_point_combined); every caller gets exactly what a lone call returns."""
+    import threading
+    X, y, Xs = parity.synthetic_real(300, 256, 77)
+    yc = 0.5 * y * np.exp(0.5j * (X[:, 0] + 10.0))
+    for cplx in (False, True):
+        fit = gpu.complex_fit([1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05], X, yc, 0) if cplx else gpu.real_fit([1.0, 0.7086, 0.7056, 1e-2], X, y, 0)
+        pred = gpu.complex_predict if cplx else gpu.real_predict
+        lone = [pred(fit, Xs[i:i + 1]) for i in range(len(Xs))]
+        got = [None] * len(Xs)
+
+        def work(k, nt):
+            for i in range(k, len(Xs), nt):
+                got[i] = pred(fit, Xs[i:i + 1])
+
+        nt = 12
+        ths = [threading.Thread(target=work, args=(k, nt)) for k in range(nt)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for a, b in zip(lone, got):
+            for key in ("prediction", "variance", "cutoff"):
+                assert np.array_equal(a[key], b[key]), key
+        # the batched entry agrees as well
+        whole = pred(fit, Xs)
+        scale = np.abs(whole["prediction"]).max()
+        assert np.abs(np.concatenate([g["prediction"] for g in got]) - whole["prediction"]).max() <= 1e-12 * scale
+        fit.release()
