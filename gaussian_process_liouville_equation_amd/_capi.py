@@ -15,6 +15,7 @@ CALC_ERROR = 0x1
 CALC_AVERAGE = 0x2
 CALC_DERIVATIVE = 0x4
 IO_DEVICE = 0x100
+PREDICT_FULL = 0x200  # contract every test row (default: far rows whose contraction cannot move the variance are skipped)
 
 # gple_real_array / gple_complex_array
 R_KERNEL, R_INVERSE, R_INVLBL, R_INVLBL_DERIV, R_LABEL, R_INVERSE_DIAG = range(6)
@@ -168,7 +169,7 @@ def _cplx(y):
 
 # every symbol include/gple.h declares (checked by tests/test_capi_symbols.py)
 GPLE_SYMBOLS = [
-    "ctx_create", "ctx_destroy", "ctx_synchronize", "ctx_trim", "status_string", "ctx_last_error", "ctx_enable_timing", "ctx_get_timing",
+    "ctx_create", "ctx_destroy", "ctx_synchronize", "ctx_trim", "status_string", "ctx_last_error", "ctx_enable_timing", "ctx_get_timing", "ctx_get_prune_stats",
     "real_gram", "complex_gram", "cutoff_factor", "predict_batch", "shard_bounds", "set_allgather_function", "real_predict_sharded", "complex_predict_sharded",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
@@ -345,6 +346,12 @@ class Api:
                                                  C.POINTER(C.c_long)]
         self._check(self.lib.gple_ctx_get_timing(self.ctx, which, C.byref(last), C.byref(total), C.byref(count)))
         return last.value, total.value, count.value
+
+    def prune_stats(self, reset=False):
+        """(contracted, seen) 128-row blocks of test points in the row-norm kernels since creation / the last reset."""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        self._check(self.lib.gple_ctx_get_prune_stats(self.ctx, C.byref(a), C.byref(b), int(bool(reset))))
+        return a.value, b.value
 
     def synchronize(self):
         if self.ctx:

@@ -141,6 +141,7 @@ static void ctx_drop(gple_ctx* ctx)
 	(void)hipStreamSynchronize(ctx->stream);
 	for (auto& e : ctx->pool) (void)hipFree(e.p);
 	if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
+	if (ctx->prune_stats) (void)hipFree(ctx->prune_stats);
 	timer_collect(ctx);
 	for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
 	if (ctx->side_stream)
@@ -758,6 +759,23 @@ extern "C"
 		for (int w = 0; w < Ctx::NTIMERS; ++w) ctx->t_last[w] = ctx->t_total[w] = 0.0, ctx->t_count[w] = 0;
 		return GPLE_OK;
 	}
+	int gple_ctx_get_prune_stats(gple_ctx* ctx, unsigned long long* contracted_blocks, unsigned long long* seen_blocks, int reset)
+	{
+		if (!ctx) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		unsigned long long h[2] = {0, 0};
+		if (ctx->prune_stats)
+		{
+			GPLE_HIP(ctx, hipMemcpyAsync(h, ctx->prune_stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+			if (reset) GPLE_HIP(ctx, hipMemsetAsync(ctx->prune_stats, 0, sizeof(h), ctx->stream));
+			GPLE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		}
+		if (contracted_blocks) *contracted_blocks = h[0];
+		if (seen_blocks) *seen_blocks = h[1];
+		return GPLE_OK;
+	}
 	int gple_ctx_get_timing(gple_ctx* ctx, gple_timer which, double* last_ms, double* total_ms, long* count)
 	{
 		if (!ctx || static_cast<int>(which) < 0 || static_cast<int>(which) >= Ctx::NTIMERS) return GPLE_ERR_BAD_ARG;
@@ -1063,6 +1081,14 @@ extern "C"
 		if (want_deriv)
 			for (int ip = 0; ip < (cplx ? 8 : 4); ++ip) scalars->error_derivative[ip] = ctx->host_scalars[HS_PRED_DERIV + ip];
 	}
+	static bool predict_pruning()
+	{
+		static const bool on = [] {
+			const char* e = getenv("GPLE_PREDICT_PRUNE");
+			return !e || atoi(e) != 0;
+		}();
+		return on;
+	}
 	static int predict_common(gple_ctx* ctx, const FitCommon* f, const double* Xs, size_t M, unsigned flags, const double* labels,
 		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars)
 	{
@@ -1104,6 +1130,17 @@ extern "C"
 		a.Xs = xs_dev, a.M = Mi, a.m_rows = m_rows, a.m_split = cplx ? Mh : m_rows;
 		a.Xt = f->Xt, a.N = f->N, a.n_total = f->n_total, a.n_split = cplx ? f->Np : f->n_total;
 		a.T = f->T, a.ldt = f->n_total, a.v = f->v, a.q = q.p, a.mu = mu.p, a.ps = f->ps;
+		if (!cplx && !(flags & GPLE_PREDICT_FULL) && predict_pruning())
+		{
+			// |k*|^2 below this cannot move the variance (gple_predict.hip, Prune): lambda_min(K) >= amp n2, k(x*,x*) = self
+			a.prune_thr = std::ldexp(f->self * f->ps.p[0].amp * f->ps.p[0].n2, -56);
+			if (!ctx->prune_stats)
+			{
+				GPLE_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->prune_stats), 2 * sizeof(unsigned long long)));
+				GPLE_HIP(ctx, hipMemsetAsync(ctx->prune_stats, 0, 2 * sizeof(unsigned long long), st));
+			}
+			a.prune_stats = ctx->prune_stats;
+		}
 		if (want_deriv)
 		{
 			GPLE_HIP(ctx, dacc.get((cplx ? 15 : 7) * static_cast<size_t>(m_rows)));

@@ -79,6 +79,8 @@ namespace gple
 		hipEvent_t side_fork = nullptr, side_join = nullptr;
 		// pinned host block for scalar results
 		double* host_scalars = nullptr;
+		// device counters of the predict path's far-row pruning: [0] blocks contracted, [1] blocks seen (lazily allocated)
+		unsigned long long* prune_stats = nullptr;
 		// tracing (gple_ctx_enable_timing): every timed interval takes an event pair from a free list and joins `pending`
 		// until the next stream synchronisation collects it, so that timing never forces a synchronisation of its own
 		struct TimedSpan

@@ -83,7 +83,7 @@ namespace gple
 		// PredictiveComplexKernel::ErrorDerivatives (complex_kernel.cpp:648-668); dc_p comes from a.dspec[p - 1].
 		template <int DERIV>
 		__global__ void __launch_bounds__(128) kstar_gen_kernel(const PredictArgs a, int row0, int rows, double* __restrict__ Ks,
-			double* __restrict__ mu_part)
+			double* __restrict__ mu_part, double* __restrict__ nrm_part)
 		{
 			const int r = blockIdx.x * 128 + threadIdx.x; // row inside the chunk
 			const int gm = row0 + r;                       // row of the typed test set
@@ -94,7 +94,7 @@ namespace gple
 			const int ksplit = gridDim.y;
 			const int kper = a.n_total / ksplit; // multiple of 4 (n_total is a multiple of 256, ksplit <= 64)
 			const int kbeg = blockIdx.y * kper;
-			double mu = 0.0;
+			double mu = 0.0, nrm = 0.0;
 			constexpr int NACC = DERIV == 2 ? 14 : 6;
 			double dacc[NACC];
 #pragma unroll
@@ -119,6 +119,7 @@ namespace gple
 					const double delta = (xm == xk && pm == pkv) ? n2 : 0.0; // delta_kernel: exact equality, kernel.cpp:26
 					const double val = valid ? amp * (g + delta) : 0.0;
 					mu = fma(val, a.v[k], mu);
+					if constexpr (DERIV == 0) nrm = fma(val, val, nrm);
 					if constexpr (DERIV == 2)
 					{
 #pragma unroll
@@ -147,6 +148,8 @@ namespace gple
 				out += 4L * rows;
 			}
 			mu_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = mu;
+			if constexpr (DERIV == 0)
+				if (nrm_part != nullptr) nrm_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = nrm;
 			if constexpr (DERIV != 0)
 #pragma unroll
 				for (int ip = 0; ip < NACC; ++ip) mu_part[(static_cast<long>(ip + 1) * ksplit + blockIdx.y) * a.m_rows + gm] = dacc[ip];
@@ -160,15 +163,63 @@ namespace gple
 			(kstep(std::integral_constant<int, (D * KB) / 16>{}, nd + D), ...);
 		}
 
+		// Rows whose K* is so small that the contraction cannot move the variance: q = k*^T K^-1 k* <= |k*|^2 / lambda_min(K) and
+		// lambda_min(K) >= sf^2 sn^2 (the ridge), so |k*|^2 < thr = 2^-56 sf^2 sn^2 k(x*,x*) leaves q below a quarter of the
+		// half-ulp of k(x*,x*): k(x*,x*) - q rounds to k(x*,x*) with or without it.  A 128-row block whose rows are all like that
+		// (grid points more than ~7 length scales away from every training point: most of a phase-space grid) writes q = 0 and
+		// returns — bit-identical output.  nrm_part[ky][row]: the generation kernel's partial sums of K*^2 over its k-ranges.
+		struct Prune
+		{
+			const double* nrm_part; // nullptr: contract everything
+			int planes;
+			long stride; // m_rows
+			int row0;    // first typed row of this chunk
+			double thr;
+			unsigned long long* stats; // [0] live blocks, [1] blocks seen (nullptr: not counted)
+		};
+		// Workgroups go to the 8 XCDs round-robin by their linear id, and the live blocks of a grid come in a pattern that repeats
+		// every few blocks (a run of p-values inside every x-column): taken in order, the live ones of the north-star grid all landed
+		// on 4 of the 8 XCDs (25.5 ms for 378 live blocks = 3 rounds on half the chip).  Inside every group of 8 consecutive row
+		// blocks the position is therefore rotated by the group index: every XCD sees every position.
+		__device__ __forceinline__ int row_block_of(int bx, int nblocks)
+		{
+			return (nblocks & 7) ? bx : ((bx & ~7) | ((bx + (bx >> 3)) & 7));
+		}
+		template <int ROWS>
+		__device__ __forceinline__ bool block_is_dead(const Prune& pr, int m0, double* __restrict__ qout)
+		{
+			if (pr.nrm_part == nullptr) return false;
+			__shared__ int live;
+			if (threadIdx.x == 0) live = 0;
+			__syncthreads();
+			if (threadIdx.x < ROWS)
+			{
+				double sq = 0.0;
+				for (int ky = 0; ky < pr.planes; ++ky) sq += pr.nrm_part[static_cast<long>(ky) * pr.stride + pr.row0 + m0 + threadIdx.x];
+				if (!(sq < pr.thr)) live = 1; // NaN counts as live
+			}
+			__syncthreads();
+			const bool dead = live == 0;
+			if (threadIdx.x == 0 && pr.stats != nullptr && blockIdx.y == 0)
+			{
+				atomicAdd(pr.stats + 1, 1ULL);
+				if (!dead) atomicAdd(pr.stats, 1ULL);
+			}
+			if (dead && threadIdx.x < ROWS) qout[m0 + threadIdx.x] = 0.0;
+			return dead;
+		}
+
 		// q[row] = sum_n ( sum_{k <= n} K*(row, k) T(n, k) )^2 for one chunk of rows.
 		// WAVES waves x 16 rows per workgroup, K advances KB per barrier.  <8, 16>: one workgroup fills a CU (2 waves per
 		// SIMD); <4, 8>: two independent workgroups per CU cover each other's barrier / pipeline-fill bubbles (selected with
 		// GPLE_ROWNORM_VARIANT for A/B runs, default chosen in launch_predict_q).
 		template <int WAVES, int KB>
 		__global__ void __launch_bounds__(WAVES * 64, 8 / WAVES) rownorm_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T,
-			long ldt, int n_total, double* __restrict__ q, long qstride)
+			long ldt, int n_total, double* __restrict__ q, long qstride, const Prune pr)
 		{
 			constexpr int TM = WAVES * 16, NT = WAVES * 64;
+			const int mblock = pr.nrm_part ? row_block_of(blockIdx.x, gridDim.x) : blockIdx.x;
+			if (block_is_dead<TM>(pr, mblock * TM, q + static_cast<long>(blockIdx.y) * qstride)) return;
 			constexpr int ASr = TM + 16;
 			constexpr int ASL = KB * ASr, BSL = KB * BS;
 			constexpr int NA = TM * KB / 2 / NT, NBv = BN * KB / 2 / NT; // double2 per thread and slab
@@ -178,7 +229,7 @@ namespace gple
 			double* const Bs = lds + 2 * ASL;
 			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
 			const int fk = lane >> 4, fr = lane & 15;
-			const int m0 = blockIdx.x * TM;
+			const int m0 = mblock * TM;
 			const int ntiles = n_total / BN;
 			double rsq = 0.0;
 
@@ -389,13 +440,15 @@ namespace gple
 		}
 		template <int AF, int BF>
 		__global__ void __launch_bounds__(NTHREADS, 1) rownorm2_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt,
-			int n_total, double* __restrict__ q, long qstride)
+			int n_total, double* __restrict__ q, long qstride, const Prune pr)
 		{
 			constexpr int KB = 16, WN = 16 / BF, ASr = BM + 16;
+			const int mblock = pr.nrm_part ? row_block_of(blockIdx.x, gridDim.x) : blockIdx.x;
+			if (block_is_dead<BM>(pr, mblock * BM, q + static_cast<long>(blockIdx.y) * qstride)) return;
 			__shared__ __attribute__((aligned(16))) double lds[2 * KB * ASr + 2 * KB * BS];
 			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 			const int wm = w / WN, wn = w % WN;
-			const int m0 = blockIdx.x * BM;
+			const int m0 = mblock * BM;
 			double rsq[AF];
 #pragma unroll
 			for (int i = 0; i < AF; ++i) rsq[i] = 0.0;
@@ -760,7 +813,8 @@ namespace gple
 		if (small) rows = a.m_rows; // one chunk (<= 512 MiB), plus Z of the same size
 		*chunk_rows = static_cast<int>(rows);
 		return rows * a.n_total + static_cast<size_t>(gen_ksplit(a.m_rows)) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1)
-			+ (small ? rows * a.n_total : 0) + static_cast<size_t>(ROWNORM_SPLIT_MAX) * a.m_rows;
+			+ (small ? rows * a.n_total : 0) + static_cast<size_t>(ROWNORM_SPLIT_MAX) * a.m_rows
+			+ (a.prune_thr > 0.0 ? static_cast<size_t>(gen_ksplit(a.m_rows)) * a.m_rows : 0);
 	}
 
 	bool predict_is_few(const PredictArgs& a)
@@ -815,15 +869,21 @@ namespace gple
 		const bool small = few_rows && chunk_rows == a.m_rows;
 		const int ksplit = gen_ksplit(a.m_rows);
 		double* Z = mu_part + static_cast<size_t>(ksplit) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1);
+		// (the group count must not depend on the pruning: the order in which a row's tile sums are added would, and with it the last
+		// bits of q — the pruned and the full predict are bit-identical because they differ in nothing but the skipped blocks)
 		const int split = small ? 1 : rownorm_split(a.m_rows, a.n_total);
 		double* qpart = Z + (small ? static_cast<size_t>(chunk_rows) * a.n_total : 0);
+		// far-row pruning (Prune): streaming kernels of the default variants, no derivative pass
+		const bool prune = a.prune_thr > 0.0 && !a.dv && !small && (variant == 0 || variant == 2 || variant == 3);
+		double* nrm_part = prune ? qpart + static_cast<size_t>(ROWNORM_SPLIT_MAX) * a.m_rows : nullptr;
 		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
 		{
 			const int rows = a.m_rows - row0 < chunk_rows ? a.m_rows - row0 : chunk_rows;
 			const dim3 ggrid(rows / 128, ksplit);
-			if (a.dv && a.complex_deriv) hipLaunchKernelGGL(kstar_gen_kernel<2>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
-			else if (a.dv) hipLaunchKernelGGL(kstar_gen_kernel<1>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
-			else hipLaunchKernelGGL(kstar_gen_kernel<0>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part);
+			const Prune pr{nrm_part, ksplit, static_cast<long>(a.m_rows), row0, a.prune_thr, a.prune_stats};
+			if (a.dv && a.complex_deriv) hipLaunchKernelGGL(kstar_gen_kernel<2>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, nrm_part);
+			else if (a.dv) hipLaunchKernelGGL(kstar_gen_kernel<1>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, nrm_part);
+			else hipLaunchKernelGGL(kstar_gen_kernel<0>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, nrm_part);
 			chunk_timer_start(ctx);
 			if (small)
 			{
@@ -836,7 +896,7 @@ namespace gple
 				if (e != hipSuccess) return e;
 				hipLaunchKernelGGL(colsumsq_kernel, dim3(rows), dim3(256), 0, s, Z, static_cast<long>(a.n_total), a.n_total, a.q + row0);
 			}
-			else if (variant == 1) hipLaunchKernelGGL((rownorm_kernel<4, 8>), dim3(rows / 64), dim3(256), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0, 0L);
+			else if (variant == 1) hipLaunchKernelGGL((rownorm_kernel<4, 8>), dim3(rows / 64), dim3(256), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0, 0L, Prune{});
 			else if (variant == 4)
 			{
 				const int G = split;
@@ -848,9 +908,9 @@ namespace gple
 				const int G = split;
 				double* qdst = G > 1 ? qpart + row0 : a.q + row0;
 				if (variant == 2)
-					hipLaunchKernelGGL((rownorm2_kernel<4, 4>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows));
+					hipLaunchKernelGGL((rownorm2_kernel<4, 4>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
 				else
-					hipLaunchKernelGGL((rownorm2_kernel<2, 8>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows));
+					hipLaunchKernelGGL((rownorm2_kernel<2, 8>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
 			}
 			else
 			{
@@ -858,7 +918,7 @@ namespace gple
 				const int G = split;
 				double* qdst = G > 1 ? qpart + row0 : a.q + row0;
 				hipLaunchKernelGGL((rownorm_kernel<8, 16>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst,
-					static_cast<long>(a.m_rows));
+					static_cast<long>(a.m_rows), pr);
 			}
 			chunk_timer_stop(ctx);
 		}

@@ -42,6 +42,11 @@ extern "C" {
 #define GPLE_CALC_DERIVATIVE 0x4u
 /* Array arguments of this call are device pointers. */
 #define GPLE_IO_DEVICE 0x100u
+/* *_predict: contract every test row.  By default a real-kernel predict skips the variance contraction for 128-row blocks of
+ * test points whose K* rows are all so small (|k*|^2 < 2^-56 sf^2 sn^2 k(x*,x*)) that k(x*,x*) - k* K^-1 k*^T rounds to
+ * k(x*,x*) whatever the contraction returns — grid points far from every training point.  The outputs are bit-identical
+ * either way; the flag exists for measurements that want the full contraction timed. */
+#define GPLE_PREDICT_FULL 0x200u
 
 #define GPLE_REAL_NPARAM 4    /* KernelBase::NumTotalParameters        kernel.h:33          */
 #define GPLE_COMPLEX_NPARAM 8 /* ComplexKernelBase::NumTotalParameters complex_kernel.h:22  */
@@ -136,6 +141,9 @@ int gple_ctx_enable_timing(gple_ctx* ctx, int on);
 /* Synchronises the stream, then: last = milliseconds of the most recent interval; total / count = accumulated since
  * enable (any may be NULL). */
 int gple_ctx_get_timing(gple_ctx* ctx, gple_timer which, double* last_ms, double* total_ms, long* count);
+/* Synchronises the stream, then: 128-row blocks of test points the row-norm kernels contracted / saw since the context was
+ * created or since the last call with reset != 0 (see GPLE_PREDICT_FULL). */
+int gple_ctx_get_prune_stats(gple_ctx* ctx, unsigned long long* contracted_blocks, unsigned long long* seen_blocks, int reset);
 
 /* ---- KernelBase (kernel.h:29-106, kernel.cpp:8-242) ---------------------------------------------- */
 /* K = sf^2 (G + sn^2 delta) for theta = (sf, lx, lp, sn), left 2 x R, right 2 x C, K is R x C column-major.

@@ -470,3 +470,39 @@ def test_one_point_predicts_from_many_threads(gpu):
         scale = np.abs(whole["prediction"]).max()
         assert np.abs(np.concatenate([g["prediction"] for g in got]) - whole["prediction"]).max() <= 1e-12 * scale
         fit.release()
+
+
+def test_far_row_pruning_is_bit_identical(gpu):
+    """A real-kernel grid predict skips the variance contraction for 128-row blocks of test points whose K* rows cannot move
+    k(x*,x*) - k* K^-1 k*^T by half an ulp (|k*|^2 < 2^-56 sf^2 sn^2 k(x*,x*), lambda_min(K) >= sf^2 sn^2): outputs with and
+    without GPLE_PREDICT_FULL agree bit for bit on the reference's grid (input.cpp:37-70: the whole phase-space box, most of it
+    far from the density), and most blocks are in fact skipped there; a grid inside the data cloud skips nothing."""
+    from tests.test_gpu_configs import config_inputs, THETA_R
+    N, G = 1024, 256
+    X, y, grid, _ = config_inputs(N, G, 1)
+    fit = gpu.real_fit(THETA_R, X, y, 0)
+    gpu.prune_stats(reset=True)
+    full = gpu.real_predict(fit, grid, flags=c.PREDICT_FULL)
+    assert gpu.prune_stats(reset=True) == (0, 0)  # the full contraction does not consult the test at all
+    pruned = gpu.real_predict(fit, grid)
+    live, seen = gpu.prune_stats(reset=True)
+    assert seen == len(grid) // 128 and 0 < live < 0.5 * seen, (live, seen)
+    for k in ("prediction", "variance", "cutoff"):
+        assert np.array_equal(full[k], pruned[k]), k
+    # the skipped rows really are prior-variance rows, the contracted ones are not all
+    prior = THETA_R[0] ** 2 * (1 + THETA_R[3] ** 2)
+    assert (pruned["variance"] == prior).mean() > 0.5 and (pruned["variance"] < 0.9 * prior).any()
+    # test points inside the cloud: nothing to skip
+    inside = X[:512] + 0.01
+    a, b = gpu.real_predict(fit, inside, flags=c.PREDICT_FULL), gpu.real_predict(fit, inside)
+    live, seen = gpu.prune_stats(reset=True)
+    assert live == seen or seen == 0  # (few-rows path: not pruned, not counted)
+    for k in ("prediction", "variance", "cutoff"):
+        assert np.array_equal(a[k], b[k]), k
+    # a noise-free kernel has no ridge to bound lambda_min with: threshold 0, nothing skipped
+    fit0 = gpu.real_fit([1.0, 0.7086, 0.7056, 0.0], X[:256], y[:256], 0)
+    gpu.real_predict(fit0, grid)
+    live, seen = gpu.prune_stats(reset=True)
+    assert live == seen
+    fit0.release()
+    fit.release()
