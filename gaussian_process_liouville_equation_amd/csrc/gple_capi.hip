@@ -1136,8 +1136,8 @@ extern "C"
 			a.prune_thr = std::ldexp(f->self * f->ps.p[0].amp * f->ps.p[0].n2, -56);
 			if (!ctx->prune_stats)
 			{
-				GPLE_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->prune_stats), 2 * sizeof(unsigned long long)));
-				GPLE_HIP(ctx, hipMemsetAsync(ctx->prune_stats, 0, 2 * sizeof(unsigned long long), st));
+				GPLE_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->prune_stats), 4 * sizeof(unsigned long long))); // [2]: the work-queue counter
+				GPLE_HIP(ctx, hipMemsetAsync(ctx->prune_stats, 0, 4 * sizeof(unsigned long long), st));
 			}
 			a.prune_stats = ctx->prune_stats;
 		}

@@ -24,6 +24,7 @@
 // the result columns (lane & 15) on the test row m, so the squared row sums stay lane-local.
 //
 // "Typed" rows/columns implement the complex GP as a real GP on [Re; Im] (see gple_kernels.h, SEParamSet).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -176,17 +177,46 @@ namespace gple
 			int row0;    // first typed row of this chunk
 			double thr;
 			unsigned long long* stats; // [0] live blocks, [1] blocks seen (nullptr: not counted)
+			// Work queue.  The dispatcher hands workgroups to (XCD, CU) slots in a fixed round-robin (measured: 512 live blocks
+			// alternating with 512 dead ones take as long as 1024 live ones; 384 live blocks take 12.7 ms when they are contiguous and
+			// 21-26 ms when they are scattered, probes/live_pattern_probe.py), so skipping blocks in place leaves the live ones stacked
+			// on whatever slots their indices map to.  With pruning on, a launch is therefore one resident workgroup per CU pulling
+			// units (row block x tile group) from this counter until it runs dry — every workgroup reaches the exit.
+			int* queue;     // device counter, zeroed before the launch; nullptr: unit = the workgroup's own index
+			int nblocks, G; // units = nblocks x G (queue mode; the grid says it otherwise)
 		};
-		// Workgroups go to the 8 XCDs round-robin by their linear id, and the live blocks of a grid come in a pattern that repeats
-		// every few blocks (a run of p-values inside every x-column): taken in order, the live ones of the north-star grid all landed
-		// on 4 of the 8 XCDs (25.5 ms for 378 live blocks = 3 rounds on half the chip).  Inside every group of 8 consecutive row
-		// blocks the position is therefore rotated by the group index: every XCD sees every position.
-		__device__ __forceinline__ int row_block_of(int bx, int nblocks)
+		// the unit this workgroup works on next: false when there is none (queue mode: the counter ran past the last unit;
+		// static mode: the one unit of the workgroup is done)
+		__device__ __forceinline__ bool next_unit(const Prune& pr, int it, int& mblock, int& g, int& G)
 		{
-			return (nblocks & 7) ? bx : ((bx & ~7) | ((bx + (bx >> 3)) & 7));
+			if (pr.queue == nullptr)
+			{
+				mblock = blockIdx.x, g = blockIdx.y, G = gridDim.y;
+				return it == 0;
+			}
+			__shared__ int s_unit;
+			if (threadIdx.x == 0) s_unit = atomicAdd(pr.queue, 1);
+			__syncthreads();
+			const int unit = __builtin_amdgcn_readfirstlane(s_unit); // uniform: keep it (and what follows from it) in SGPRs
+			__syncthreads();
+			G = pr.G;
+			mblock = unit % pr.nblocks, g = unit / pr.nblocks;
+			return unit < pr.nblocks * pr.G;
+		}
+		// A row's squared norm is the sum over the N-tiles of T; which workgroup adds which tiles depends on how many groups the launch
+		// splits a row block into (rownorm_split: by the number of row blocks).  So that the VALUE does not depend on that choice,
+		// the tiles are dealt out to VG fixed "virtual groups" in snake order (tile jt costs jt + 1 units), every virtual group
+		// keeps its own partial sum q[vg][row], and the planes are added in the fixed order 0 .. VG - 1 afterwards.  A launch with
+		// G groups gives group g the virtual groups snake_G(vg) == g.  Same bits for G = 1, 2, 4, 8 — a batch, its pieces, the
+		// pruned and the full predict all agree.
+		constexpr int VG = 8;
+		__device__ __forceinline__ int snake(int v, int G)
+		{
+			const int p = v % (2 * G);
+			return p < G ? p : 2 * G - 1 - p;
 		}
 		template <int ROWS>
-		__device__ __forceinline__ bool block_is_dead(const Prune& pr, int m0, double* __restrict__ qout)
+		__device__ __forceinline__ bool block_is_dead(const Prune& pr, int m0, double* __restrict__ qout, long qstride, int G, int g)
 		{
 			if (pr.nrm_part == nullptr) return false;
 			__shared__ int live;
@@ -200,26 +230,25 @@ namespace gple
 			}
 			__syncthreads();
 			const bool dead = live == 0;
-			if (threadIdx.x == 0 && pr.stats != nullptr && blockIdx.y == 0)
+			if (threadIdx.x == 0 && pr.stats != nullptr && g == 0)
 			{
 				atomicAdd(pr.stats + 1, 1ULL);
 				if (!dead) atomicAdd(pr.stats, 1ULL);
 			}
-			if (dead && threadIdx.x < ROWS) qout[m0 + threadIdx.x] = 0.0;
+			if (dead && threadIdx.x < ROWS)
+				for (int vg = 0; vg < VG; ++vg)
+					if (snake(vg, G) == g) qout[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = 0.0;
 			return dead;
 		}
 
 		// q[row] = sum_n ( sum_{k <= n} K*(row, k) T(n, k) )^2 for one chunk of rows.
-		// WAVES waves x 16 rows per workgroup, K advances KB per barrier.  <8, 16>: one workgroup fills a CU (2 waves per
-		// SIMD); <4, 8>: two independent workgroups per CU cover each other's barrier / pipeline-fill bubbles (selected with
-		// GPLE_ROWNORM_VARIANT for A/B runs, default chosen in launch_predict_q).
+		// WAVES waves x 16 rows per workgroup, K advances KB per barrier.  <8, 16> (the one launched): one workgroup fills a CU
+		// (2 waves per SIMD).  GPLE_ROWNORM_VARIANT selects between this kernel and rownorm2_kernel for A/B runs (launch_predict_q).
 		template <int WAVES, int KB>
 		__global__ void __launch_bounds__(WAVES * 64, 8 / WAVES) rownorm_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T,
 			long ldt, int n_total, double* __restrict__ q, long qstride, const Prune pr)
 		{
 			constexpr int TM = WAVES * 16, NT = WAVES * 64;
-			const int mblock = pr.nrm_part ? row_block_of(blockIdx.x, gridDim.x) : blockIdx.x;
-			if (block_is_dead<TM>(pr, mblock * TM, q + static_cast<long>(blockIdx.y) * qstride)) return;
 			constexpr int ASr = TM + 16;
 			constexpr int ASL = KB * ASr, BSL = KB * BS;
 			constexpr int NA = TM * KB / 2 / NT, NBv = BN * KB / 2 / NT; // double2 per thread and slab
@@ -229,7 +258,7 @@ namespace gple
 			double* const Bs = lds + 2 * ASL;
 			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
 			const int fk = lane >> 4, fr = lane & 15;
-			const int m0 = mblock * TM;
+			int m0 = 0; // row block of the current unit (the loaders below read it)
 			const int ntiles = n_total / BN;
 			double rsq = 0.0;
 
@@ -274,11 +303,18 @@ namespace gple
 			// gridDim.y > 1 splits the N-tiles of one row block over several workgroups (few row blocks: fill the chip anyway).
 			// N-tile jt costs jt + 1 units, so the tiles are dealt out in snake order: group g of G takes the tiles whose
 			// position in a period of 2 G is g or 2 G - 1 - g.
-			const int G = gridDim.y, g = blockIdx.y;
+			int mblock, g, G;
+			for (int it = 0; next_unit(pr, it, mblock, g, G); ++it)
+			{
+			m0 = mblock * TM;
+			if (block_is_dead<TM>(pr, m0, q, qstride, G, g)) continue;
+			for (int vg = 0; vg < VG; ++vg)
+			{
+			if (snake(vg, G) != g) continue; // uniform
+			rsq = 0.0;
 			for (int jt = 0; jt < ntiles; ++jt)
 			{
-				const int pos = jt % (2 * G);
-				if ((pos < G ? pos : 2 * G - 1 - pos) != g) continue; // uniform; no accumulator is live here
+				if (snake(jt, VG) != vg) continue; // uniform; no accumulator is live here
 				const int n0 = jt * BN;
 				const int nk = (n0 + BN) / KB; // T(n,k) = 0 for k > n: k-slabs beyond the N-tile's last column are skipped
 				d4 acc[16];
@@ -324,7 +360,9 @@ namespace gple
 			}
 			rsq += __shfl_xor(rsq, 16);
 			rsq += __shfl_xor(rsq, 32);
-			if (lane < 16) q[static_cast<long>(g) * qstride + m0 + w * 16 + lane] = rsq; // partial sums of tile group g
+			if (lane < 16) q[static_cast<long>(vg) * qstride + m0 + w * 16 + lane] = rsq; // partial sums of virtual group vg
+			}
+			}
 		}
 
 		// ---- register-blocked variant ------------------------------------------------------------------------------------
@@ -338,7 +376,7 @@ namespace gple
 		// straight-line code (branches around live accumulators make hipcc spill): the tile loop is instantiated per wn.
 		template <int AF, int BF, int WNI>
 		__device__ __forceinline__ void rownorm2_tiles(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt, int n_total,
-			double* lds, double (&rsq)[AF], int m0, int wm)
+			double* lds, double (&rsq)[AF], int m0, int wm, int vg)
 		{
 			constexpr int KB = 16, TM = BM, NT = NTHREADS, WN = 16 / BF;
 			constexpr int ASr = TM + 16;
@@ -386,11 +424,9 @@ namespace gple
 					*reinterpret_cast<d2*>(sb + k * BS + r2) = breg[qq];
 				}
 			};
-			const int G = gridDim.y, g = blockIdx.y;
 			for (int jt = 0; jt < ntiles; ++jt)
 			{
-				const int pos = jt % (2 * G);
-				if ((pos < G ? pos : 2 * G - 1 - pos) != g) continue; // uniform; no accumulator is live here
+				if (snake(jt, VG) != vg) continue; // uniform; no accumulator is live here
 				const int n0 = jt * BN;
 				const int nk = (n0 + BN) / KB;
 				d4 acc[AF][BF];
@@ -443,168 +479,56 @@ namespace gple
 			int n_total, double* __restrict__ q, long qstride, const Prune pr)
 		{
 			constexpr int KB = 16, WN = 16 / BF, ASr = BM + 16;
-			const int mblock = pr.nrm_part ? row_block_of(blockIdx.x, gridDim.x) : blockIdx.x;
-			if (block_is_dead<BM>(pr, mblock * BM, q + static_cast<long>(blockIdx.y) * qstride)) return;
 			__shared__ __attribute__((aligned(16))) double lds[2 * KB * ASr + 2 * KB * BS];
 			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 			const int wm = w / WN, wn = w % WN;
+			int mblock, g, G;
+			for (int it = 0; next_unit(pr, it, mblock, g, G); ++it)
+			{
 			const int m0 = mblock * BM;
-			double rsq[AF];
+			if (block_is_dead<BM>(pr, m0, q, qstride, G, g)) continue;
+			for (int vg = 0; vg < VG; ++vg)
+			{
+				if (snake(vg, G) != g) continue; // uniform
+				double rsq[AF];
 #pragma unroll
-			for (int i = 0; i < AF; ++i) rsq[i] = 0.0;
-			// the tile loop once per column index of the wave (uniform branch, taken once; no accumulator is live across it)
-			if constexpr (WN == 4)
-			{
-				if (wn == 0) rownorm2_tiles<AF, BF, 0>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
-				else if (wn == 1) rownorm2_tiles<AF, BF, 1>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
-				else if (wn == 2) rownorm2_tiles<AF, BF, 2>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
-				else rownorm2_tiles<AF, BF, 3>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
-			}
-			else
-			{
-				if (wn == 0) rownorm2_tiles<AF, BF, 0>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
-				else rownorm2_tiles<AF, BF, 1>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
-			}
-			// rows of fragment i: m0 + wm * 16 AF + 16 i + (lane & 15); partial sums of the WN column groups meet in LDS
-			__syncthreads();
+				for (int i = 0; i < AF; ++i) rsq[i] = 0.0;
+				// the tile loop once per column index of the wave (uniform branch, taken once; no accumulator is live across it)
+				if constexpr (WN == 4)
+				{
+					if (wn == 0) rownorm2_tiles<AF, BF, 0>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm, vg);
+					else if (wn == 1) rownorm2_tiles<AF, BF, 1>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm, vg);
+					else if (wn == 2) rownorm2_tiles<AF, BF, 2>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm, vg);
+					else rownorm2_tiles<AF, BF, 3>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm, vg);
+				}
+				else
+				{
+					if (wn == 0) rownorm2_tiles<AF, BF, 0>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm, vg);
+					else rownorm2_tiles<AF, BF, 1>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm, vg);
+				}
+				// rows of fragment i: m0 + wm * 16 AF + 16 i + (lane & 15); partial sums of the WN column groups meet in LDS
+				__syncthreads();
 #pragma unroll
-			for (int i = 0; i < AF; ++i)
-			{
-				double v = rsq[i];
-				v += __shfl_xor(v, 16);
-				v += __shfl_xor(v, 32);
-				if (lane < 16) lds[wn * BM + wm * (16 * AF) + 16 * i + lane] = v;
-			}
-			__syncthreads();
-			if (threadIdx.x < BM)
-			{
-				double v = 0.0;
+				for (int i = 0; i < AF; ++i)
+				{
+					double v = rsq[i];
+					v += __shfl_xor(v, 16);
+					v += __shfl_xor(v, 32);
+					if (lane < 16) lds[wn * BM + wm * (16 * AF) + 16 * i + lane] = v;
+				}
+				__syncthreads();
+				if (threadIdx.x < BM)
+				{
+					double v = 0.0;
 #pragma unroll
-				for (int c = 0; c < WN; ++c) v += lds[c * BM + threadIdx.x];
-				q[static_cast<long>(blockIdx.y) * qstride + m0 + threadIdx.x] = v;
+					for (int c = 0; c < WN; ++c) v += lds[c * BM + threadIdx.x];
+					q[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = v;
+				}
+				__syncthreads(); // the next virtual group's first tile stages operands over these sums
+			}
 			}
 		}
 
-		// ---- two independent workgroups per CU -------------------------------------------------------------------------------
-		// In the kernels above the two waves that share a SIMD belong to the same workgroup: they meet the same barrier every
-		// k-step and wait for their LDS operands at the same moments, so neither covers the other's stalls (SQ_WAIT_ANY 15 % of
-		// the wave cycles ~ the idle share of the MFMA pipe).  Here a workgroup is 4 waves (one per SIMD) on a 128 x 128 tile,
-		// each wave 4 x 4 fragments (64 rows x 64 columns, 8 operand reads per 16 MFMAs); its 74 KB of LDS let TWO workgroups
-		// share a CU, and the two waves of a SIMD then come from different workgroups with unrelated barriers.  Price: K* is
-		// re-read once per 128-column tile of T instead of per 256 (twice the HBM stream, still far below the roofline).
-		constexpr int BN3 = 128, BS3 = BN3 + 16, NT3 = 256;
-		template <int WNI>
-		__device__ __forceinline__ void rownorm3_tiles(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt, int n_total,
-			double* lds, double (&rsq)[4], int m0, int wm)
-		{
-			constexpr int KB = 16, AF = 4, BF = 4, WN = 2;
-			constexpr int ASr = BM + 16;
-			constexpr int ASL = KB * ASr, BSL = KB * BS3;
-			constexpr int NA = BM * KB / 2 / NT3, NBv = BN3 * KB / 2 / NT3; // 4 + 4 double2 per thread and slab
-			double* const As = lds;
-			double* const Bs = lds + 2 * ASL;
-			const int t = threadIdx.x, lane = t & 63;
-			const int fk = lane >> 4, fr = lane & 15;
-			const int ntiles = n_total / BN3;
-			d2 areg[NA], breg[NBv];
-			auto load_ab = [&](int n0, int k0) {
-				const double* __restrict__ abase = Ks + m0 + static_cast<long>(k0) * rows;
-				const double* __restrict__ bbase = T + n0 + static_cast<long>(k0) * ldt;
-#pragma unroll
-				for (int qq = 0; qq < NA; ++qq)
-				{
-					const int i = t + NT3 * qq;
-					const int r2 = (i & 63) * 2, k = i >> 6;
-					areg[qq] = *reinterpret_cast<const d2*>(abase + r2 + static_cast<long>(k) * rows);
-					breg[qq] = *reinterpret_cast<const d2*>(bbase + r2 + static_cast<long>(k) * ldt);
-				}
-			};
-			auto store_ab = [&](int buf) {
-				double* __restrict__ sa = As + buf * ASL;
-				double* __restrict__ sb = Bs + buf * BSL;
-#pragma unroll
-				for (int qq = 0; qq < NA; ++qq)
-				{
-					const int i = t + NT3 * qq;
-					const int r2 = (i & 63) * 2, k = i >> 6;
-					*reinterpret_cast<d2*>(sa + k * ASr + r2) = areg[qq];
-					*reinterpret_cast<d2*>(sb + k * BS3 + r2) = breg[qq];
-				}
-			};
-			const int G = gridDim.y, g = blockIdx.y;
-			for (int jt = 0; jt < ntiles; ++jt)
-			{
-				const int pos = jt % (2 * G);
-				if ((pos < G ? pos : 2 * G - 1 - pos) != g) continue;
-				const int n0 = jt * BN3;
-				const int nk = (n0 + BN3) / KB;
-				d4 acc[AF][BF];
-#pragma unroll
-				for (int i = 0; i < AF; ++i)
-#pragma unroll
-					for (int j = 0; j < BF; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-				__syncthreads();
-				load_ab(n0, 0);
-				store_ab(0);
-				__syncthreads();
-				auto kstep = [&](auto tmin_tag, int s) {
-					constexpr int TMIN = decltype(tmin_tag)::value;
-					if (s + 1 < nk) load_ab(n0, (s + 1) * KB);
-					const double* __restrict__ pa = As + (s & 1) * ASL + wm * 64 + fr;
-					const double* __restrict__ pb = Bs + (s & 1) * BSL + WNI * 16 + fr;
-#pragma unroll
-					for (int kk = 0; kk < KB; kk += 4)
-					{
-						double af[AF], bf[BF];
-#pragma unroll
-						for (int i = 0; i < AF; ++i) af[i] = pa[(kk + fk) * ASr + i * 16];
-#pragma unroll
-						for (int j = TMIN; j < BF; ++j) bf[j] = pb[(kk + fk) * BS3 + j * (16 * WN)];
-#pragma unroll
-						for (int i = 0; i < AF; ++i)
-#pragma unroll
-							for (int j = TMIN; j < BF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
-					}
-					if (s + 1 < nk) store_ab((s + 1) & 1);
-					__syncthreads();
-				};
-				const int nd = n0 / KB;
-				for (int s = 0; s < nd; ++s) kstep(std::integral_constant<int, 0>{}, s);
-				// diagonal 128-block: 8 k-steps, column block jb = WNI + 2 t is zero for jb < D
-				[&]<int... D>(std::integer_sequence<int, D...>) {
-					(kstep(std::integral_constant<int, (D > WNI ? (D - WNI + WN - 1) / WN : 0)>{}, nd + D), ...);
-				}(std::make_integer_sequence<int, BN3 / KB>{});
-#pragma unroll
-				for (int i = 0; i < AF; ++i)
-#pragma unroll
-					for (int j = 0; j < BF; ++j)
-#pragma unroll
-						for (int r = 0; r < 4; ++r) rsq[i] = fma(acc[i][j][r], acc[i][j][r], rsq[i]);
-			}
-		}
-		__global__ void __launch_bounds__(NT3, 2) rownorm3_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt,
-			int n_total, double* __restrict__ q, long qstride)
-		{
-			constexpr int KB = 16, ASr = BM + 16;
-			__shared__ __attribute__((aligned(16))) double lds[2 * KB * ASr + 2 * KB * BS3];
-			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-			const int wm = w >> 1, wn = w & 1;
-			const int m0 = blockIdx.x * BM;
-			double rsq[4] = {0.0, 0.0, 0.0, 0.0};
-			if (wn == 0) rownorm3_tiles<0>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
-			else rownorm3_tiles<1>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm);
-			__syncthreads();
-#pragma unroll
-			for (int i = 0; i < 4; ++i)
-			{
-				double v = rsq[i];
-				v += __shfl_xor(v, 16);
-				v += __shfl_xor(v, 32);
-				if (lane < 16) lds[wn * BM + wm * 64 + 16 * i + lane] = v;
-			}
-			__syncthreads();
-			if (threadIdx.x < BM) q[static_cast<long>(blockIdx.y) * qstride + m0 + threadIdx.x] = lds[threadIdx.x] + lds[BM + threadIdx.x];
-		}
 
 		// ---- a handful of test points (the one-point predicts of main.cpp:75-101, evolve.cpp:298, mc.cpp:158-172) --------------
 		// For M <= FEW_MAX typed rows the tiled paths pad to 128 rows, materialise K* and run a GEMM against all of T: 0.1-0.65 ms
@@ -792,6 +716,15 @@ namespace gple
 			}
 			return best;
 		}
+		int device_cu_count()
+		{
+			static const int n = [] {
+				int dev = 0, cus = 256;
+				if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+				return cus > 0 ? cus : 256;
+			}();
+			return n;
+		}
 		bool small_m(const PredictArgs& a)
 		{
 			const bool fits = static_cast<size_t>(a.m_rows) * a.n_total <= SMALL_M_Z_DOUBLES;
@@ -856,9 +789,10 @@ namespace gple
 		if (a.M <= 0) return hipSuccess;
 		if (a.m_rows % BM || a.n_total % BN || a.m_split % BM || a.n_split % BN || chunk_rows % BM || chunk_rows <= 0)
 			return hipErrorInvalidValue;
-		// 0: 8 waves x (16 rows x 256 columns); 1: 4 waves, BK 8, two workgroups per CU; 2 / 3: 8 waves x (4 x 4) / (2 x 8) fragments;
-		// 4: 4 waves x (4 x 4) on a 128 x 128 tile, two workgroups per CU.  Measured at C2 / C4r (TFLOP/s, same box): 60.1 / 65.07,
-		// — / 61 (round 1), 59.6 / 65.78, 60.4 / 65.75, 60.0 / 64.02.  Default: 2 from eight N-tiles on (+1.1 % at C4r), else 0.
+		// 0: 8 waves x (16 rows x 256 columns); 2 / 3: 8 waves x (4 x 4) / (2 x 8) fragments.  Measured at C2 / C4r (TFLOP/s, same
+		// box): 60.1 / 65.07, 59.6 / 65.78, 60.4 / 65.75 (two more shapes — 4 waves with BK 8, and 4 waves on a 128 x 128 tile, both
+		// with two workgroups per CU — were 61 and 64.0 at C4r and are gone; profiles/r02_notes.md).  Default: 2 from eight N-tiles
+		// on (+1.1 % at C4r), else 0.
 		static const int forced = [] {
 			const char* e = getenv("GPLE_ROWNORM_VARIANT");
 			return e ? atoi(e) : -1;
@@ -869,18 +803,24 @@ namespace gple
 		const bool small = few_rows && chunk_rows == a.m_rows;
 		const int ksplit = gen_ksplit(a.m_rows);
 		double* Z = mu_part + static_cast<size_t>(ksplit) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1);
-		// (the group count must not depend on the pruning: the order in which a row's tile sums are added would, and with it the last
-		// bits of q — the pruned and the full predict are bit-identical because they differ in nothing but the skipped blocks)
-		const int split = small ? 1 : rownorm_split(a.m_rows, a.n_total);
+		// groups per row block: by the number of row blocks (rownorm_split); the value of q does not depend on it (virtual groups).
+		// With far-row pruning the live blocks are a fraction of the launch and smaller units pack the CUs better (378 live blocks of
+		// the north-star grid: 3 rounds of whole blocks behind the dead ones = 25 ms, 3 rounds of half blocks = 12.5 ms)
+		int split = small ? 1 : rownorm_split(a.m_rows, a.n_total);
 		double* qpart = Z + (small ? static_cast<size_t>(chunk_rows) * a.n_total : 0);
 		// far-row pruning (Prune): streaming kernels of the default variants, no derivative pass
-		const bool prune = a.prune_thr > 0.0 && !a.dv && !small && (variant == 0 || variant == 2 || variant == 3);
+		const bool prune = a.prune_thr > 0.0 && !a.dv && !small && a.prune_stats != nullptr;
+		if (prune && split < 2 && a.n_total / BN >= 4) split = 2;
 		double* nrm_part = prune ? qpart + static_cast<size_t>(ROWNORM_SPLIT_MAX) * a.m_rows : nullptr;
 		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
 		{
 			const int rows = a.m_rows - row0 < chunk_rows ? a.m_rows - row0 : chunk_rows;
 			const dim3 ggrid(rows / 128, ksplit);
-			const Prune pr{nrm_part, ksplit, static_cast<long>(a.m_rows), row0, a.prune_thr, a.prune_stats};
+			// pruning: one resident workgroup per CU (a few more in case some are held by other streams) pulls the units from a queue
+			const int nblocks = rows / BM;
+			int* queue = prune ? reinterpret_cast<int*>(a.prune_stats + 2) : nullptr;
+			const Prune pr{nrm_part, ksplit, static_cast<long>(a.m_rows), row0, a.prune_thr, a.prune_stats, queue, nblocks, split};
+			const dim3 rgrid = prune ? dim3(std::min(nblocks * split, 2 * device_cu_count())) : dim3(nblocks, split);
 			if (a.dv && a.complex_deriv) hipLaunchKernelGGL(kstar_gen_kernel<2>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, nrm_part);
 			else if (a.dv) hipLaunchKernelGGL(kstar_gen_kernel<1>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, nrm_part);
 			else hipLaunchKernelGGL(kstar_gen_kernel<0>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, nrm_part);
@@ -896,33 +836,23 @@ namespace gple
 				if (e != hipSuccess) return e;
 				hipLaunchKernelGGL(colsumsq_kernel, dim3(rows), dim3(256), 0, s, Z, static_cast<long>(a.n_total), a.n_total, a.q + row0);
 			}
-			else if (variant == 1) hipLaunchKernelGGL((rownorm_kernel<4, 8>), dim3(rows / 64), dim3(256), 0, s, Ks, rows, a.T, a.ldt, a.n_total, a.q + row0, 0L, Prune{});
-			else if (variant == 4)
-			{
-				const int G = split;
-				double* qdst = G > 1 ? qpart + row0 : a.q + row0;
-				hipLaunchKernelGGL(rownorm3_kernel, dim3(rows / BM, G), dim3(NT3), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows));
-			}
-			else if (variant == 2 || variant == 3)
-			{
-				const int G = split;
-				double* qdst = G > 1 ? qpart + row0 : a.q + row0;
-				if (variant == 2)
-					hipLaunchKernelGGL((rownorm2_kernel<4, 4>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
-				else
-					hipLaunchKernelGGL((rownorm2_kernel<2, 8>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
-			}
 			else
 			{
-				// fewer than two workgroups per CU: split the N-tiles of every row block over G workgroups (partial sums)
-				const int G = split;
-				double* qdst = G > 1 ? qpart + row0 : a.q + row0;
-				hipLaunchKernelGGL((rownorm_kernel<8, 16>), dim3(rows / BM, G), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst,
-					static_cast<long>(a.m_rows), pr);
+				if (prune)
+				{
+					const hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), s);
+					if (e != hipSuccess) return e;
+				}
+				if (variant == 3)
+					hipLaunchKernelGGL((rownorm2_kernel<2, 8>), rgrid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows), pr);
+				else if (variant == 2)
+					hipLaunchKernelGGL((rownorm2_kernel<4, 4>), rgrid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows), pr);
+				else
+					hipLaunchKernelGGL((rownorm_kernel<8, 16>), rgrid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows), pr);
 			}
 			chunk_timer_stop(ctx);
 		}
-		if (split > 1) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, qpart, a.m_rows, split, a.q);
+		if (!small) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, qpart, a.m_rows, VG, a.q); // the VG planes, in order
 		// a.mu receives plane 0 (the mean); with derivatives a.dacc receives all 7 planes (plane 0 = the mean again)
 		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.mu);
 		if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, a.complex_deriv ? 15 : 7), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.dacc);
