@@ -324,7 +324,7 @@ def main():
     }
     if args.prune:
         result["config"]["workload"] += " [--prune: far rows not contracted]"
-    if world == 1 and not cplx and not args.prune:
+    if world == 1 and not args.prune:
         full_out = last["full"].clone()
         predict_mode["flag"] = 0
         api.prune_stats(reset=True)

@@ -1130,10 +1130,13 @@ extern "C"
 		a.Xs = xs_dev, a.M = Mi, a.m_rows = m_rows, a.m_split = cplx ? Mh : m_rows;
 		a.Xt = f->Xt, a.N = f->N, a.n_total = f->n_total, a.n_split = cplx ? f->Np : f->n_total;
 		a.T = f->T, a.ldt = f->n_total, a.v = f->v, a.q = q.p, a.mu = mu.p, a.ps = f->ps;
-		if (!cplx && !(flags & GPLE_PREDICT_FULL) && predict_pruning())
+		if (!(flags & GPLE_PREDICT_FULL) && predict_pruning())
 		{
-			// |k*|^2 below this cannot move the variance (gple_predict.hip, Prune): lambda_min(K) >= amp n2, k(x*,x*) = self
-			a.prune_thr = std::ldexp(f->self * f->ps.p[0].amp * f->ps.p[0].n2, -56);
+			// |k*|^2 below this cannot move the variance (gple_predict.hip, Prune): lambda_min(K) >= amp n2, k(x*,x*) = self.
+			// Complex GP in its [Re; Im] embedding: the covariance is a valid (positive semi-definite) cross-covariance of two
+			// squared-exponential processes plus s^2 sn^2 / 2 on the whole diagonal (p[0].amp p[0].n2 = p[2].amp p[2].n2), and the
+			// variance subtracts the contractions of TWO typed rows per point: half the budget each.
+			a.prune_thr = std::ldexp(f->self * f->ps.p[0].amp * f->ps.p[0].n2, cplx ? -57 : -56);
 			if (!ctx->prune_stats)
 			{
 				GPLE_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->prune_stats), 4 * sizeof(unsigned long long))); // [2]: the work-queue counter

@@ -506,3 +506,18 @@ def test_far_row_pruning_is_bit_identical(gpu):
     assert live == seen
     fit0.release()
     fit.release()
+
+
+def test_far_row_pruning_complex_is_bit_identical(gpu):
+    """the same for the complex GP (two typed rows per point in the [Re; Im] embedding, lambda_min >= s^2 sn^2 / 2)"""
+    from tests.test_gpu_configs import config_inputs, THETA_C
+    X, y, grid, _ = config_inputs(512, 256, 3, cplx=True)
+    fit = gpu.complex_fit(THETA_C, X, y, 0)
+    full = gpu.complex_predict(fit, grid, flags=c.PREDICT_FULL)
+    gpu.prune_stats(reset=True)
+    pruned = gpu.complex_predict(fit, grid)
+    live, seen = gpu.prune_stats(reset=True)
+    assert seen == 2 * len(grid) // 128 and 0 < live < 0.6 * seen, (live, seen)
+    for k in ("prediction", "variance", "cutoff"):
+        assert np.array_equal(full[k], pruned[k]), k
+    fit.release()
