@@ -182,14 +182,15 @@ namespace gple
 			// 21-26 ms when they are scattered, probes/live_pattern_probe.py), so skipping blocks in place leaves the live ones stacked
 			// on whatever slots their indices map to.  With pruning on, a launch is therefore one resident workgroup per CU pulling
 			// units (row block x tile group) from this counter until it runs dry — every workgroup reaches the exit.
-			int* queue;     // device counter, zeroed before the launch; nullptr: unit = the workgroup's own index
+			int* queue;     // device counter, zeroed before the launch (kernels instantiated with QUEUE = true; the others take their own index)
 			int nblocks, G; // units = nblocks x G (queue mode; the grid says it otherwise)
 		};
 		// the unit this workgroup works on next: false when there is none (queue mode: the counter ran past the last unit;
 		// static mode: the one unit of the workgroup is done)
+		template <bool QUEUE>
 		__device__ __forceinline__ bool next_unit(const Prune& pr, int it, int& mblock, int& g, int& G)
 		{
-			if (pr.queue == nullptr)
+			if constexpr (!QUEUE)
 			{
 				mblock = blockIdx.x, g = blockIdx.y, G = gridDim.y;
 				return it == 0;
@@ -244,7 +245,7 @@ namespace gple
 		// q[row] = sum_n ( sum_{k <= n} K*(row, k) T(n, k) )^2 for one chunk of rows.
 		// WAVES waves x 16 rows per workgroup, K advances KB per barrier.  <8, 16> (the one launched): one workgroup fills a CU
 		// (2 waves per SIMD).  GPLE_ROWNORM_VARIANT selects between this kernel and rownorm2_kernel for A/B runs (launch_predict_q).
-		template <int WAVES, int KB>
+		template <int WAVES, int KB, bool QUEUE>
 		__global__ void __launch_bounds__(WAVES * 64, 8 / WAVES) rownorm_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T,
 			long ldt, int n_total, double* __restrict__ q, long qstride, const Prune pr)
 		{
@@ -304,7 +305,7 @@ namespace gple
 			// N-tile jt costs jt + 1 units, so the tiles are dealt out in snake order: group g of G takes the tiles whose
 			// position in a period of 2 G is g or 2 G - 1 - g.
 			int mblock, g, G;
-			for (int it = 0; next_unit(pr, it, mblock, g, G); ++it)
+			for (int it = 0; next_unit<QUEUE>(pr, it, mblock, g, G); ++it)
 			{
 			m0 = mblock * TM;
 			if (block_is_dead<TM>(pr, m0, q, qstride, G, g)) continue;
@@ -474,7 +475,7 @@ namespace gple
 						for (int r = 0; r < 4; ++r) rsq[i] = fma(acc[i][j][r], acc[i][j][r], rsq[i]);
 			}
 		}
-		template <int AF, int BF>
+		template <int AF, int BF, bool QUEUE>
 		__global__ void __launch_bounds__(NTHREADS, 1) rownorm2_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt,
 			int n_total, double* __restrict__ q, long qstride, const Prune pr)
 		{
@@ -483,7 +484,7 @@ namespace gple
 			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 			const int wm = w / WN, wn = w % WN;
 			int mblock, g, G;
-			for (int it = 0; next_unit(pr, it, mblock, g, G); ++it)
+			for (int it = 0; next_unit<QUEUE>(pr, it, mblock, g, G); ++it)
 			{
 			const int m0 = mblock * BM;
 			if (block_is_dead<BM>(pr, m0, q, qstride, G, g)) continue;
@@ -843,12 +844,13 @@ namespace gple
 					const hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), s);
 					if (e != hipSuccess) return e;
 				}
-				if (variant == 3)
-					hipLaunchKernelGGL((rownorm2_kernel<2, 8>), rgrid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows), pr);
-				else if (variant == 2)
-					hipLaunchKernelGGL((rownorm2_kernel<4, 4>), rgrid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows), pr);
-				else
-					hipLaunchKernelGGL((rownorm_kernel<8, 16>), rgrid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows), pr);
+				auto launch = [&](auto full_kernel, auto queue_kernel) {
+					if (prune) hipLaunchKernelGGL(queue_kernel, rgrid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows), pr);
+					else hipLaunchKernelGGL(full_kernel, rgrid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows), pr);
+				};
+				if (variant == 3) launch(rownorm2_kernel<2, 8, false>, rownorm2_kernel<2, 8, true>);
+				else if (variant == 2) launch(rownorm2_kernel<4, 4, false>, rownorm2_kernel<4, 4, true>);
+				else launch(rownorm_kernel<8, 16, false>, rownorm_kernel<8, 16, true>);
 			}
 			chunk_timer_stop(ctx);
 		}
