@@ -1591,13 +1591,25 @@ extern "C"
 			}();
 			return fn;
 		}
-		// gathered[r][...] (world blocks of (2 ow + 1) * per doubles: mean | var | cut of rank r's slice) -> full-length outputs
-		__global__ void __launch_bounds__(256) unshard_kernel(const double* __restrict__ g, size_t per, int ow, size_t M, double* __restrict__ mean,
+		// Block-cyclic deal of the test points: 128-point block b belongs to rank b % world (local block b / world).  Contiguous
+		// slices would balance the full contraction just as well, but with far-row pruning (the default) the live blocks of a
+		// phase-space grid sit in one corner of it and a contiguous slice holds anything between all and none of them.
+		constexpr size_t SHARD_BLOCK = 128;
+		__global__ void __launch_bounds__(256) shard_points_kernel(const double* __restrict__ Xs, size_t M, int rank, int world, size_t n_local,
+			double* __restrict__ out)
+		{
+			const size_t j = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+			if (j >= n_local) return;
+			const size_t i = ((j / SHARD_BLOCK) * world + rank) * SHARD_BLOCK + j % SHARD_BLOCK;
+			out[2 * j] = Xs[2 * i], out[2 * j + 1] = Xs[2 * i + 1];
+		}
+		// gathered[r][...] (world blocks of (2 ow + 1) * per doubles: mean | var | cut of rank r's points) -> full-length outputs
+		__global__ void __launch_bounds__(256) unshard_kernel(const double* __restrict__ g, size_t per, int ow, size_t M, int world, double* __restrict__ mean,
 			double* __restrict__ var, double* __restrict__ cut)
 		{
 			const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
 			if (i >= M) return;
-			const size_t r = i / per, q = i % per;
+			const size_t b = i / SHARD_BLOCK, r = b % world, q = (b / world) * SHARD_BLOCK + i % SHARD_BLOCK;
 			const double* __restrict__ blk = g + r * (2 * ow + 1) * per;
 			for (int k = 0; k < ow; ++k)
 			{
@@ -1615,12 +1627,11 @@ extern "C"
 	static int predict_sharded(gple_ctx* ctx, const FitCommon* f, const double* Xs, size_t M, unsigned flags, int rank, int world, void* comm,
 		double* prediction, double* variance, double* cutoff_prediction)
 	{
-		size_t lo, hi, per;
-		GPLE_TRY(gple_shard_bounds(M, rank, world, &lo, &hi, &per));
+		if (world < 1 || rank < 0 || rank >= world) return GPLE_ERR_BAD_ARG;
 		if (world > 1 && !comm) return GPLE_ERR_BAD_ARG;
 		if (M == 0) return GPLE_OK;
 		const bool dev = flags & GPLE_IO_DEVICE;
-		if (!comm) return predict_common(ctx, f, Xs, M, flags & GPLE_IO_DEVICE, nullptr, prediction, variance, cutoff_prediction, nullptr);
+		if (!comm) return predict_common(ctx, f, Xs, M, flags & (GPLE_IO_DEVICE | GPLE_PREDICT_FULL), nullptr, prediction, variance, cutoff_prediction, nullptr);
 		const allgather_fn allgather = resolve_allgather();
 		if (!allgather)
 		{
@@ -1628,26 +1639,38 @@ extern "C"
 			ctx->last_error = std::string("ncclAllGather not found: ") + (dlerror() ? dlerror() : "librccl is not loadable");
 			return GPLE_ERR_COLLECTIVE;
 		}
+		// this rank's points: the 128-point blocks rank, rank + world, ... (the last block of the set may be short)
+		const size_t nblocks = (M + SHARD_BLOCK - 1) / SHARD_BLOCK, per = (nblocks + world - 1) / world * SHARD_BLOCK;
+		const size_t my_blocks = nblocks > static_cast<size_t>(rank) ? (nblocks - rank + world - 1) / world : 0;
+		size_t n_local = my_blocks * SHARD_BLOCK;
+		if (my_blocks && ((my_blocks - 1) * world + rank) == nblocks - 1) n_local -= nblocks * SHARD_BLOCK - M; // owner of the short block
 		const size_t ow = f->is_complex ? 2 : 1, blk = (2 * ow + 1) * per;
 		hipStream_t st = ctx->stream;
-		// the slice goes through device buffers whatever the caller's pointers are: the collective runs on device memory
-		Scratch local(ctx), gathered(ctx), xs(ctx), om(ctx), ov(ctx), oc(ctx);
-		const double* xs_dev = Xs + 2 * lo;
+		// the points go through device buffers whatever the caller's pointers are: the collective runs on device memory
+		Scratch local(ctx), gathered(ctx), xs_all(ctx), xs(ctx), om(ctx), ov(ctx), oc(ctx);
 		{
 			std::lock_guard<std::mutex> lk(ctx->call_mu);
 			GPLE_HIP(ctx, hipSetDevice(ctx->device));
 			GPLE_HIP(ctx, local.get(blk));
 			GPLE_HIP(ctx, gathered.get(blk * world));
-			GPLE_HIP(ctx, hipMemsetAsync(local.p, 0, blk * 8, st)); // the padded tail of the last rank's slice
-			if (!dev && hi > lo)
+			GPLE_HIP(ctx, hipMemsetAsync(local.p, 0, blk * 8, st)); // the padded tail of the ranks with fewer points
+			const double* all_dev = Xs;
+			if (!dev)
 			{
-				GPLE_HIP(ctx, xs.get(2 * (hi - lo)));
-				GPLE_HIP(ctx, copy_in(st, xs.p, Xs + 2 * lo, 2 * (hi - lo), false));
-				xs_dev = xs.p;
+				GPLE_HIP(ctx, xs_all.get(2 * M));
+				GPLE_HIP(ctx, copy_in(st, xs_all.p, Xs, 2 * M, false));
+				all_dev = xs_all.p;
+			}
+			if (n_local)
+			{
+				GPLE_HIP(ctx, xs.get(2 * n_local));
+				hipLaunchKernelGGL(shard_points_kernel, dim3(static_cast<unsigned>((n_local + 255) / 256)), dim3(256), 0, st, all_dev, M, rank, world, n_local, xs.p);
+				GPLE_HIP(ctx, hipGetLastError());
 			}
 		}
-		if (hi > lo)
-			GPLE_TRY(predict_common(ctx, f, xs_dev, hi - lo, GPLE_IO_DEVICE, nullptr, local.p, local.p + ow * per, local.p + (ow + 1) * per, nullptr));
+		if (n_local)
+			GPLE_TRY(predict_common(ctx, f, xs.p, n_local, GPLE_IO_DEVICE | (flags & GPLE_PREDICT_FULL), nullptr, local.p, local.p + ow * per, local.p + (ow + 1) * per,
+				nullptr));
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		const int rc = allgather(local.p, gathered.p, blk, /* ncclDouble */ 8, comm, st);
@@ -1676,7 +1699,8 @@ extern "C"
 				d_cut = oc.p;
 			}
 		}
-		hipLaunchKernelGGL(unshard_kernel, dim3(static_cast<unsigned>((M + 255) / 256)), dim3(256), 0, st, gathered.p, per, static_cast<int>(ow), M, d_mean, d_var, d_cut);
+		hipLaunchKernelGGL(unshard_kernel, dim3(static_cast<unsigned>((M + 255) / 256)), dim3(256), 0, st, gathered.p, per, static_cast<int>(ow), M, world, d_mean, d_var,
+			d_cut);
 		GPLE_HIP(ctx, hipGetLastError());
 		if (!dev)
 		{

@@ -222,11 +222,14 @@ int gple_objective_release(gple_objective* objective);
 
 /* ---- grid-sharded predict for C++ callers (output.cpp:181-233 over several GPUs) ---------------------- */
 /* One process per GPU; every rank holds the same fit (replicated: DESIGN.md §7) and calls this with the WHOLE grid Xs (2M).
- * The rank predicts its contiguous slice [lo, hi) of gple_shard_bounds and the slices are all-gathered with ncclAllGather on
- * the context's stream (RCCL over xGMI), so that prediction / variance / cutoff_prediction (each nullable, full length M resp.
+ * The rank predicts its share of the points — the 128-point blocks rank, rank + world, ... (block-cyclic, so that the live
+ * blocks of a mostly empty phase-space grid spread over the ranks, see GPLE_PREDICT_FULL) — and the shares are all-gathered
+ * with ncclAllGather on the context's stream (RCCL over xGMI), so that prediction / variance / cutoff_prediction (each nullable, full length M resp.
  * 2M for the complex kernel) are complete on every rank when the call returns (host outputs) or when the stream reaches that
  * point (GPLE_IO_DEVICE).  nccl_comm is the caller's ncclComm_t; the RCCL entry points are resolved at first use from the
  * process (the caller links librccl) or from librccl.so.1.  world == 1 with nccl_comm == NULL is the plain predict. */
+/* For callers that shard by hand (contiguous slices, what bench.py / parallel.py do): slice [lo, hi) of M points for rank, and
+ * the padded slice length `per` every rank allocates. */
 int gple_shard_bounds(size_t M, int rank, int world, size_t* lo, size_t* hi, size_t* per);
 /* Callers with another transport (MPI, host staging) plug their own all-gather: same signature and semantics as
  * ncclAllGather(sendbuff, recvbuff, sendcount, datatype = 8 (double), comm, hipStream_t), device buffers, 0 = success.

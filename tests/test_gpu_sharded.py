@@ -1,4 +1,4 @@
-"""GPU: the grid-sharded predict of the C-ABI (gple_*_predict_sharded: slice -> predict -> ncclAllGather -> unpack), the native
+"""GPU: the grid-sharded predict of the C-ABI (gple_*_predict_sharded: block-cyclic share -> predict -> ncclAllGather -> unpack), the native
 counterpart of parallel.GridShardedStep for C++ callers (output.cpp:181-233 over several GPUs).
   * real RCCL with a one-rank communicator (a one-GPU box cannot hold two RCCL ranks on one device);
   * world = 2 and 3 as host threads with separate contexts on the one GPU, through an in-process all-gather plugged in with
@@ -80,15 +80,21 @@ def test_sharded_predict_between_threads(gpu, world, cplx):
     gpu.lib.gple_set_allgather_function.argtypes = [C.c_void_p]
     gpu.lib.gple_set_allgather_function(C.cast(fake.fake_allgather, C.c_void_p))
     try:
-        M = 1001  # not a multiple of world: the last slice is shorter than `per`
+        M = 1001  # 8 blocks of 128, the last one short: the ranks hold different numbers of points
         X, yr, Xs = parity.synthetic_real(150, M, 9)
         y = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0)) if cplx else yr
         theta = [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05] if cplx else [1.0, 0.7086, 0.7056, 1e-2]
-        # reference: the unsharded slices, one call per slice (the split of the mean's k-sum depends on the rows of a call)
+        # reference: every rank's share (the 128-point blocks r, r + world, ...) in one unsharded call each (the split of the
+        # mean's k-sum depends on the rows of a call), scattered back to grid order
         fit0 = (gpu.complex_fit if cplx else gpu.real_fit)(theta, X, y, 0)
         pred = gpu.complex_predict if cplx else gpu.real_predict
-        parts = [pred(fit0, Xs[lo:hi]) for lo, hi, _ in (parallel.shard_bounds(M, r, world) for r in range(world))]
-        ref = {k: np.concatenate([p[k] for p in parts]) for k in ("prediction", "variance", "cutoff")}
+        ref = {"prediction": np.empty(M, dtype=complex if cplx else float), "variance": np.empty(M), "cutoff": np.empty(M, dtype=complex if cplx else float)}
+        block = np.arange(M) // 128
+        for r in range(world):
+            idx = np.nonzero(block % world == r)[0]
+            part = pred(fit0, Xs[idx])
+            for k in ref:
+                ref[k][idx] = part[k]
         group = fake.fake_group_create(world)
         out, errs = {}, []
 
