@@ -82,13 +82,23 @@ namespace gple
 		// PredictiveKernel::ErrorDerivatives (kernel.cpp:524-542); mu_part then holds 7 planes of gridDim.y x m_rows.
 		// DERIV = 2 (complex GP in the [Re; Im] embedding): 15 planes [c w, c dw_0..7, dc_1..6 w] for
 		// PredictiveComplexKernel::ErrorDerivatives (complex_kernel.cpp:648-668); dc_p comes from a.dspec[p - 1].
-		template <int DERIV>
+		// MODE 0: K* of the rows [row0, row0 + rows) and the partial means (the full predict).  Far-row pruning runs it twice:
+		// MODE 1 over all rows without storing K* (partial means and the partial sums of K*^2 that decide which rows are live), then
+		// MODE 2 over the compacted list of live rows (row0 = offset into the list; K* only).
+		template <int DERIV, int MODE>
 		__global__ void __launch_bounds__(128) kstar_gen_kernel(const PredictArgs a, int row0, int rows, double* __restrict__ Ks,
-			double* __restrict__ mu_part, double* __restrict__ nrm_part)
+			double* __restrict__ mu_part, double* __restrict__ nrm_part, const int* __restrict__ live_list, const int* __restrict__ n_live)
 		{
 			const int r = blockIdx.x * 128 + threadIdx.x; // row inside the chunk
-			const int gm = row0 + r;                       // row of the typed test set
-			const int type_m = (row0 + blockIdx.x * 128) >= a.m_split; // uniform per block (m_split multiple of 128)
+			int gm = row0 + r;                             // row of the typed test set
+			int type_m = (row0 + blockIdx.x * 128) >= a.m_split; // MODE 0, 1: uniform per block (m_split multiple of 128)
+			if constexpr (MODE == 2)
+			{
+				const int nl = *n_live;
+				if (row0 + static_cast<int>(blockIdx.x) * 128 >= nl) return; // uniform: nothing live in this block of the list
+				gm = live_list[gm < nl ? gm : nl - 1];                        // the tail of the last block repeats the last live row (never read back)
+				type_m = gm >= a.m_split;                                      // per lane: the list mixes the two row types of a complex GP
+			}
 			int pidx = type_m ? gm - a.m_split : gm;
 			pidx = pidx < a.M ? pidx : a.M - 1; // rows beyond M are clamped (their results are never read)
 			const double xm = a.Xs[2 * pidx], pm = a.Xs[2 * pidx + 1];
@@ -104,9 +114,9 @@ namespace gple
 			for (int k0 = kbeg; k0 < kbeg + kper; k0 += 4)
 			{
 				const int type_k = k0 >= a.n_split;
-				const SEParam& p = a.ps.p[type_m + type_k];
-				const double n2 = (type_m == type_k) ? p.n2 : 0.0;
-				const double amp = p.amp, rl0 = p.rl0, rl1 = p.rl1;
+				const SEParam &pa = a.ps.p[type_k], &pb = a.ps.p[1 + type_k]; // row type 0 / 1 against this column type
+				const double amp = type_m ? pb.amp : pa.amp, rl0 = type_m ? pb.rl0 : pa.rl0, rl1 = type_m ? pb.rl1 : pa.rl1;
+				const double n2 = (type_m == type_k) ? (type_m ? pb.n2 : pa.n2) : 0.0;
 #pragma unroll
 				for (int e = 0; e < 4; ++e)
 				{
@@ -119,8 +129,8 @@ namespace gple
 					const double g = exp_nonpos(-0.5 * (d0 * d0 + d1 * d1));
 					const double delta = (xm == xk && pm == pkv) ? n2 : 0.0; // delta_kernel: exact equality, kernel.cpp:26
 					const double val = valid ? amp * (g + delta) : 0.0;
-					mu = fma(val, a.v[k], mu);
-					if constexpr (DERIV == 0) nrm = fma(val, val, nrm);
+					if constexpr (MODE != 2) mu = fma(val, a.v[k], mu);
+					if constexpr (MODE == 1) nrm = fma(val, val, nrm);
 					if constexpr (DERIV == 2)
 					{
 #pragma unroll
@@ -144,13 +154,12 @@ namespace gple
 						dacc[4] = fma(vk, d0 * d0 * rl0, dacc[4]);
 						dacc[5] = fma(vk, d1 * d1 * rl1, dacc[5]);
 					}
-					out[static_cast<long>(e) * rows] = val;
+					if constexpr (MODE != 1) out[static_cast<long>(e) * rows] = val;
 				}
 				out += 4L * rows;
 			}
-			mu_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = mu;
-			if constexpr (DERIV == 0)
-				if (nrm_part != nullptr) nrm_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = nrm;
+			if constexpr (MODE != 2) mu_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = mu;
+			if constexpr (MODE == 1) nrm_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = nrm;
 			if constexpr (DERIV != 0)
 #pragma unroll
 				for (int ip = 0; ip < NACC; ++ip) mu_part[(static_cast<long>(ip + 1) * ksplit + blockIdx.y) * a.m_rows + gm] = dacc[ip];
@@ -166,24 +175,22 @@ namespace gple
 
 		// Rows whose K* is so small that the contraction cannot move the variance: q = k*^T K^-1 k* <= |k*|^2 / lambda_min(K) and
 		// lambda_min(K) >= sf^2 sn^2 (the ridge), so |k*|^2 < thr = 2^-56 sf^2 sn^2 k(x*,x*) leaves q below a quarter of the
-		// half-ulp of k(x*,x*): k(x*,x*) - q rounds to k(x*,x*) with or without it.  A 128-row block whose rows are all like that
-		// (grid points more than ~7 length scales away from every training point: most of a phase-space grid) writes q = 0 and
-		// returns — bit-identical output.  nrm_part[ky][row]: the generation kernel's partial sums of K*^2 over its k-ranges.
+		// half-ulp of k(x*,x*): k(x*,x*) - q rounds to k(x*,x*) with or without it — grid points more than ~7 length scales away
+		// from every training point: most of a phase-space grid.  Such rows get q = 0 and are not contracted; the others are
+		// compacted into a list, K* is generated for the list only, and the row-norm kernel walks the compacted rows.  The output is
+		// bit-identical to the full contraction (a row's q depends on nothing but its own K* row and T).
+		//
+		// Work queue.  The dispatcher hands workgroups to (XCD, CU) slots in a fixed round-robin (measured: 512 live blocks
+		// alternating with 512 dead ones take as long as 1024 live ones; 384 live blocks take 12.7 ms when they are contiguous and
+		// 21-26 ms when they are scattered, probes/live_pattern_probe.py), and the number of live rows is only known on the device:
+		// a pruned launch is therefore one resident workgroup per CU pulling (row block, tile group) units from a counter until it
+		// runs past the last live block — every workgroup reaches that exit.
 		struct Prune
 		{
-			const double* nrm_part; // nullptr: contract everything
-			int planes;
-			long stride; // m_rows
-			int row0;    // first typed row of this chunk
-			double thr;
-			unsigned long long* stats; // [0] live blocks, [1] blocks seen (nullptr: not counted)
-			// Work queue.  The dispatcher hands workgroups to (XCD, CU) slots in a fixed round-robin (measured: 512 live blocks
-			// alternating with 512 dead ones take as long as 1024 live ones; 384 live blocks take 12.7 ms when they are contiguous and
-			// 21-26 ms when they are scattered, probes/live_pattern_probe.py), so skipping blocks in place leaves the live ones stacked
-			// on whatever slots their indices map to.  With pruning on, a launch is therefore one resident workgroup per CU pulling
-			// units (row block x tile group) from this counter until it runs dry — every workgroup reaches the exit.
-			int* queue;     // device counter, zeroed before the launch (kernels instantiated with QUEUE = true; the others take their own index)
-			int nblocks, G; // units = nblocks x G (queue mode; the grid says it otherwise)
+			int* queue;        // device counter, zeroed before the launch
+			const int* n_live; // device: number of live rows (the compacted list's length)
+			int row0;          // offset of this chunk in the compacted list
+			int nblocks, G;    // row blocks of the chunk (upper bound: the live ones are the first ceil((n_live - row0) / 128)), tile groups
 		};
 		// the unit this workgroup works on next: false when there is none (queue mode: the counter ran past the last unit;
 		// static mode: the one unit of the workgroup is done)
@@ -195,15 +202,50 @@ namespace gple
 				mblock = blockIdx.x, g = blockIdx.y, G = gridDim.y;
 				return it == 0;
 			}
-			__shared__ int s_unit;
-			if (threadIdx.x == 0) s_unit = atomicAdd(pr.queue, 1);
+			__shared__ int s_unit, s_nb;
+			if (threadIdx.x == 0)
+			{
+				s_unit = atomicAdd(pr.queue, 1);
+				const int left = *pr.n_live - pr.row0;
+				const int nb = left <= 0 ? 0 : (left + BM - 1) / BM;
+				s_nb = nb < pr.nblocks ? nb : pr.nblocks;
+			}
 			__syncthreads();
-			const int unit = __builtin_amdgcn_readfirstlane(s_unit); // uniform: keep it (and what follows from it) in SGPRs
+			const int unit = __builtin_amdgcn_readfirstlane(s_unit), nb = __builtin_amdgcn_readfirstlane(s_nb); // uniform: SGPRs
 			__syncthreads();
 			G = pr.G;
-			mblock = unit % pr.nblocks, g = unit / pr.nblocks;
-			return unit < pr.nblocks * pr.G;
+			if (unit >= nb * pr.G) return false;
+			mblock = unit % nb, g = unit / nb;
+			return true;
 		}
+		// live rows -> list (any order: rows are independent) and row -> position in the list (-1: dead)
+		__global__ void __launch_bounds__(256) compact_rows_kernel(const double* __restrict__ nrm_part, int planes, int m_rows, double thr,
+			int* __restrict__ list, int* __restrict__ pos, int* __restrict__ n_live)
+		{
+			const int row = blockIdx.x * 256 + threadIdx.x;
+			bool live = false;
+			if (row < m_rows)
+			{
+				double sq = 0.0;
+				for (int ky = 0; ky < planes; ++ky) sq += nrm_part[static_cast<long>(ky) * m_rows + row];
+				live = !(sq < thr); // NaN counts as live
+			}
+			const unsigned long long mask = __ballot(live);
+			const int lane = threadIdx.x & 63;
+			int base = 0;
+			if (lane == 0 && mask) base = atomicAdd(n_live, __popcll(mask));
+			base = __shfl(base, 0);
+			if (row < m_rows)
+			{
+				const int p = live ? base + __popcll(mask & ((1ULL << lane) - 1)) : -1;
+				pos[row] = p;
+				if (live) list[p] = row;
+			}
+		}
+		// q[row] = sum of the VG planes at the row's list position (fixed order), 0 for a dead row; statistics
+		__global__ void __launch_bounds__(256) scatter_q_kernel(const double* __restrict__ qpart, long qstride, const int* __restrict__ pos, int m_rows,
+			double* __restrict__ q, const int* __restrict__ n_live, unsigned long long* __restrict__ stats);
+
 		// A row's squared norm is the sum over the N-tiles of T; which workgroup adds which tiles depends on how many groups the launch
 		// splits a row block into (rownorm_split: by the number of row blocks).  So that the VALUE does not depend on that choice,
 		// the tiles are dealt out to VG fixed "virtual groups" in snake order (tile jt costs jt + 1 units), every virtual group
@@ -216,30 +258,21 @@ namespace gple
 			const int p = v % (2 * G);
 			return p < G ? p : 2 * G - 1 - p;
 		}
-		template <int ROWS>
-		__device__ __forceinline__ bool block_is_dead(const Prune& pr, int m0, double* __restrict__ qout, long qstride, int G, int g)
+		__global__ void __launch_bounds__(256) scatter_q_kernel(const double* __restrict__ qpart, long qstride, const int* __restrict__ pos, int m_rows,
+			double* __restrict__ q, const int* __restrict__ n_live, unsigned long long* __restrict__ stats)
 		{
-			if (pr.nrm_part == nullptr) return false;
-			__shared__ int live;
-			if (threadIdx.x == 0) live = 0;
-			__syncthreads();
-			if (threadIdx.x < ROWS)
+			const int row = blockIdx.x * 256 + threadIdx.x;
+			if (row == 0 && stats != nullptr)
 			{
-				double sq = 0.0;
-				for (int ky = 0; ky < pr.planes; ++ky) sq += pr.nrm_part[static_cast<long>(ky) * pr.stride + pr.row0 + m0 + threadIdx.x];
-				if (!(sq < pr.thr)) live = 1; // NaN counts as live
+				atomicAdd(stats, static_cast<unsigned long long>((*n_live + BM - 1) / BM));
+				atomicAdd(stats + 1, static_cast<unsigned long long>(m_rows / BM));
 			}
-			__syncthreads();
-			const bool dead = live == 0;
-			if (threadIdx.x == 0 && pr.stats != nullptr && g == 0)
-			{
-				atomicAdd(pr.stats + 1, 1ULL);
-				if (!dead) atomicAdd(pr.stats, 1ULL);
-			}
-			if (dead && threadIdx.x < ROWS)
-				for (int vg = 0; vg < VG; ++vg)
-					if (snake(vg, G) == g) qout[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = 0.0;
-			return dead;
+			if (row >= m_rows) return;
+			const int p = pos[row];
+			double v = 0.0;
+			if (p >= 0)
+				for (int vg = 0; vg < VG; ++vg) v += qpart[static_cast<long>(vg) * qstride + p];
+			q[row] = v;
 		}
 
 		// q[row] = sum_n ( sum_{k <= n} K*(row, k) T(n, k) )^2 for one chunk of rows.
@@ -308,7 +341,6 @@ namespace gple
 			for (int it = 0; next_unit<QUEUE>(pr, it, mblock, g, G); ++it)
 			{
 			m0 = mblock * TM;
-			if (block_is_dead<TM>(pr, m0, q, qstride, G, g)) continue;
 			for (int vg = 0; vg < VG; ++vg)
 			{
 			if (snake(vg, G) != g) continue; // uniform
@@ -487,7 +519,6 @@ namespace gple
 			for (int it = 0; next_unit<QUEUE>(pr, it, mblock, g, G); ++it)
 			{
 			const int m0 = mblock * BM;
-			if (block_is_dead<BM>(pr, m0, q, qstride, G, g)) continue;
 			for (int vg = 0; vg < VG; ++vg)
 			{
 				if (snake(vg, G) != g) continue; // uniform
@@ -748,7 +779,7 @@ namespace gple
 		*chunk_rows = static_cast<int>(rows);
 		return rows * a.n_total + static_cast<size_t>(gen_ksplit(a.m_rows)) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1)
 			+ (small ? rows * a.n_total : 0) + static_cast<size_t>(ROWNORM_SPLIT_MAX) * a.m_rows
-			+ (a.prune_thr > 0.0 ? static_cast<size_t>(gen_ksplit(a.m_rows)) * a.m_rows : 0);
+			+ (a.prune_thr > 0.0 ? (static_cast<size_t>(gen_ksplit(a.m_rows)) + 1) * a.m_rows + 64 : 0); // + K*^2 sums, list and positions (2 ints per row)
 	}
 
 	bool predict_is_few(const PredictArgs& a)
@@ -804,57 +835,79 @@ namespace gple
 		const bool small = few_rows && chunk_rows == a.m_rows;
 		const int ksplit = gen_ksplit(a.m_rows);
 		double* Z = mu_part + static_cast<size_t>(ksplit) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1);
-		// groups per row block: by the number of row blocks (rownorm_split); the value of q does not depend on it (virtual groups).
-		// With far-row pruning the live blocks are a fraction of the launch and smaller units pack the CUs better (378 live blocks of
-		// the north-star grid: 3 rounds of whole blocks behind the dead ones = 25 ms, 3 rounds of half blocks = 12.5 ms)
+		// groups per row block: by the number of row blocks (rownorm_split); the value of q does not depend on it (virtual groups)
 		int split = small ? 1 : rownorm_split(a.m_rows, a.n_total);
 		double* qpart = Z + (small ? static_cast<size_t>(chunk_rows) * a.n_total : 0);
-		// far-row pruning (Prune): streaming kernels of the default variants, no derivative pass
+		// far-row pruning (Prune): streaming kernels only, no derivative pass
 		const bool prune = a.prune_thr > 0.0 && !a.dv && !small && a.prune_stats != nullptr;
-		if (prune && split < 2 && a.n_total / BN >= 4) split = 2;
-		double* nrm_part = prune ? qpart + static_cast<size_t>(ROWNORM_SPLIT_MAX) * a.m_rows : nullptr;
-		for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
+		auto launch_rownorm = [&](bool queue_mode, dim3 grid, int rows, double* qdst, const Prune& pr) {
+			auto launch = [&](auto full_kernel, auto queue_kernel) {
+				if (queue_mode) hipLaunchKernelGGL(queue_kernel, grid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
+				else hipLaunchKernelGGL(full_kernel, grid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
+			};
+			if (variant == 3) launch(rownorm2_kernel<2, 8, false>, rownorm2_kernel<2, 8, true>);
+			else if (variant == 2) launch(rownorm2_kernel<4, 4, false>, rownorm2_kernel<4, 4, true>);
+			else launch(rownorm_kernel<8, 16, false>, rownorm_kernel<8, 16, true>);
+		};
+		if (prune)
 		{
-			const int rows = a.m_rows - row0 < chunk_rows ? a.m_rows - row0 : chunk_rows;
-			const dim3 ggrid(rows / 128, ksplit);
-			// pruning: one resident workgroup per CU (a few more in case some are held by other streams) pulls the units from a queue
-			const int nblocks = rows / BM;
-			int* queue = prune ? reinterpret_cast<int*>(a.prune_stats + 2) : nullptr;
-			const Prune pr{nrm_part, ksplit, static_cast<long>(a.m_rows), row0, a.prune_thr, a.prune_stats, queue, nblocks, split};
-			const dim3 rgrid = prune ? dim3(std::min(nblocks * split, 2 * device_cu_count())) : dim3(nblocks, split);
-			if (a.dv && a.complex_deriv) hipLaunchKernelGGL(kstar_gen_kernel<2>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, nrm_part);
-			else if (a.dv) hipLaunchKernelGGL(kstar_gen_kernel<1>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, nrm_part);
-			else hipLaunchKernelGGL(kstar_gen_kernel<0>, ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, nrm_part);
-			chunk_timer_start(ctx);
-			if (small)
+			// 1. partial means and partial sums of K*^2 of every row (no K* stored); 2. the live rows -> list; 3. per chunk OF THE LIST:
+			// K* of the listed rows, row norms by a work queue; 4. q back to the rows.  The number of live rows stays on the device:
+			// launches that turn out to have nothing to do return at once.
+			double* nrm_part = qpart + static_cast<size_t>(VG) * a.m_rows;
+			int* list = reinterpret_cast<int*>(nrm_part + static_cast<size_t>(ksplit) * a.m_rows);
+			int* pos = list + a.m_rows;
+			int* n_live = reinterpret_cast<int*>(a.prune_stats + 3);
+			int* queue = reinterpret_cast<int*>(a.prune_stats + 2);
+			hipError_t e = hipMemsetAsync(n_live, 0, sizeof(int), s);
+			if (e != hipSuccess) return e;
+			hipLaunchKernelGGL((kstar_gen_kernel<0, 1>), dim3(a.m_rows / 128, ksplit), dim3(128), 0, s, a, 0, a.m_rows, Ks, mu_part, nrm_part,
+				static_cast<const int*>(nullptr), static_cast<const int*>(nullptr));
+			hipLaunchKernelGGL(compact_rows_kernel, dim3((a.m_rows + 255) / 256), dim3(256), 0, s, nrm_part, ksplit, a.m_rows, a.prune_thr, list, pos, n_live);
+			// the live rows are few: at least two groups per block make better units for the queue (2 % more work when all rows are live)
+			if (split < 2 && a.n_total / BN >= 4) split = 2;
+			for (int c0 = 0; c0 < a.m_rows; c0 += chunk_rows)
 			{
-				GemmDesc g{};
-				g.A = a.T, g.lda = a.ldt, g.B = Ks, g.ldb = rows, g.C = Z, g.ldc = a.n_total;
-				g.M = a.n_total, g.N = rows, g.K = a.n_total, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
-				g.krange = K_LE_M; // T(n, k) = 0 for k > n
-				g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
-				const hipError_t e = launch_gemm(s, g, gemm_pick_tile(a.n_total, rows, 1, true));
-				if (e != hipSuccess) return e;
-				hipLaunchKernelGGL(colsumsq_kernel, dim3(rows), dim3(256), 0, s, Z, static_cast<long>(a.n_total), a.n_total, a.q + row0);
+				const int rows = a.m_rows - c0 < chunk_rows ? a.m_rows - c0 : chunk_rows;
+				hipLaunchKernelGGL((kstar_gen_kernel<0, 2>), dim3(rows / 128, ksplit), dim3(128), 0, s, a, c0, rows, Ks, mu_part, nrm_part, list, n_live);
+				if ((e = hipMemsetAsync(queue, 0, sizeof(int), s)) != hipSuccess) return e;
+				const int nblocks = rows / BM;
+				const Prune pr{queue, n_live, c0, nblocks, split};
+				chunk_timer_start(ctx);
+				launch_rownorm(true, dim3(std::min(nblocks * split, 2 * device_cu_count())), rows, qpart + c0, pr);
+				chunk_timer_stop(ctx);
 			}
-			else
-			{
-				if (prune)
-				{
-					const hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), s);
-					if (e != hipSuccess) return e;
-				}
-				auto launch = [&](auto full_kernel, auto queue_kernel) {
-					if (prune) hipLaunchKernelGGL(queue_kernel, rgrid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows), pr);
-					else hipLaunchKernelGGL(full_kernel, rgrid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows), pr);
-				};
-				if (variant == 3) launch(rownorm2_kernel<2, 8, false>, rownorm2_kernel<2, 8, true>);
-				else if (variant == 2) launch(rownorm2_kernel<4, 4, false>, rownorm2_kernel<4, 4, true>);
-				else launch(rownorm_kernel<8, 16, false>, rownorm_kernel<8, 16, true>);
-			}
-			chunk_timer_stop(ctx);
+			hipLaunchKernelGGL(scatter_q_kernel, dim3((a.m_rows + 255) / 256), dim3(256), 0, s, qpart, static_cast<long>(a.m_rows), pos, a.m_rows, a.q, n_live,
+				a.prune_stats);
 		}
-		if (!small) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, qpart, a.m_rows, VG, a.q); // the VG planes, in order
+		else
+		{
+			for (int row0 = 0; row0 < a.m_rows; row0 += chunk_rows)
+			{
+				const int rows = a.m_rows - row0 < chunk_rows ? a.m_rows - row0 : chunk_rows;
+				const dim3 ggrid(rows / 128, ksplit);
+				const int* none = nullptr;
+				if (a.dv && a.complex_deriv) hipLaunchKernelGGL((kstar_gen_kernel<2, 0>), ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, static_cast<double*>(nullptr), none, none);
+				else if (a.dv) hipLaunchKernelGGL((kstar_gen_kernel<1, 0>), ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, static_cast<double*>(nullptr), none, none);
+				else hipLaunchKernelGGL((kstar_gen_kernel<0, 0>), ggrid, dim3(128), 0, s, a, row0, rows, Ks, mu_part, static_cast<double*>(nullptr), none, none);
+				chunk_timer_start(ctx);
+				if (small)
+				{
+					GemmDesc g{};
+					g.A = a.T, g.lda = a.ldt, g.B = Ks, g.ldb = rows, g.C = Z, g.ldc = a.n_total;
+					g.M = a.n_total, g.N = rows, g.K = a.n_total, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
+					g.krange = K_LE_M; // T(n, k) = 0 for k > n
+					g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
+					const hipError_t e = launch_gemm(s, g, gemm_pick_tile(a.n_total, rows, 1, true));
+					if (e != hipSuccess) return e;
+					hipLaunchKernelGGL(colsumsq_kernel, dim3(rows), dim3(256), 0, s, Z, static_cast<long>(a.n_total), a.n_total, a.q + row0);
+				}
+				else
+					launch_rownorm(false, dim3(rows / BM, split), rows, qpart + row0, Prune{});
+				chunk_timer_stop(ctx);
+			}
+			if (!small) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, qpart, a.m_rows, VG, a.q); // the VG planes, in order
+		}
 		// a.mu receives plane 0 (the mean); with derivatives a.dacc receives all 7 planes (plane 0 = the mean again)
 		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.mu);
 		if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, a.complex_deriv ? 15 : 7), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.dacc);
