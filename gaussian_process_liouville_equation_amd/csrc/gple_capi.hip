@@ -1758,13 +1758,13 @@ extern "C"
 			if (el.real)
 			{
 				cut.resize(m);
-				GPLE_TRY(predict_common(ctx, el.real, pts.data(), m, 0u, nullptr, nullptr, nullptr, cut.data(), nullptr));
+				GPLE_TRY(predict_common(ctx, el.real, pts.data(), m, GPLE_PREDICT_FULL, nullptr, nullptr, nullptr, cut.data(), nullptr));
 				for (size_t q = 0; q < m; ++q) out[2 * req[q]] = cut[q], out[2 * req[q] + 1] = 0.0;
 			}
 			else
 			{
 				cut.resize(2 * m);
-				GPLE_TRY(predict_common(ctx, el.cplx, pts.data(), m, 0u, nullptr, nullptr, nullptr, cut.data(), nullptr));
+				GPLE_TRY(predict_common(ctx, el.cplx, pts.data(), m, GPLE_PREDICT_FULL, nullptr, nullptr, nullptr, cut.data(), nullptr));
 				for (size_t q = 0; q < m; ++q) out[2 * req[q]] = cut[2 * q], out[2 * req[q] + 1] = cut[2 * q + 1];
 			}
 		}
@@ -1801,7 +1801,9 @@ extern "C"
 		if (el.real && el.cplx) return GPLE_ERR_BAD_ARG;
 		if (m == 0 || (!el.real && !el.cplx)) return GPLE_OK;
 		const FitCommon* f = el.real ? static_cast<const FitCommon*>(el.real) : static_cast<const FitCommon*>(el.cplx);
-		return predict_common(ctx, f, pts_dev, m, GPLE_IO_DEVICE, nullptr, nullptr, nullptr, out_dev, nullptr);
+		// (the points of a tick sit on or next to the sampled density: nothing to prune, and the row statistics would cost a second
+		// generation pass)
+		return predict_common(ctx, f, pts_dev, m, GPLE_IO_DEVICE | GPLE_PREDICT_FULL, nullptr, nullptr, nullptr, out_dev, nullptr);
 	}
 
 	int gple_evolve(gple_ctx* ctx, const gple_element elements[3], int pes_model, double mass, double dt, gple_points density[3], unsigned flags)
@@ -1928,7 +1930,7 @@ extern "C"
 			gple_real_fit_scalars sc;
 			gple_real_fit* fit = nullptr;
 			GPLE_TRY(gple_real_fit_create(ctx, x, X, y, 1, N, flags | io, nullptr, &fit));
-			int st = gple_real_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io | PREDICT_NO_SYNC, lab, nullptr, nullptr, nullptr, &ps);
+			int st = gple_real_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io | PREDICT_NO_SYNC | GPLE_PREDICT_FULL, lab, nullptr, nullptr, nullptr, &ps);
 			if (st == GPLE_OK) st = gple_real_fit_get_scalars(fit, &sc); // drains the stream
 			gple_real_fit_release(fit);
 			GPLE_TRY(st);
@@ -1942,7 +1944,7 @@ extern "C"
 			gple_complex_fit_scalars sc;
 			gple_complex_fit* fit = nullptr;
 			GPLE_TRY(gple_complex_fit_create(ctx, x, X, y, N, flags | io, nullptr, &fit));
-			int st = gple_complex_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io | PREDICT_NO_SYNC, y_extra, nullptr, nullptr, nullptr, &ps);
+			int st = gple_complex_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io | PREDICT_NO_SYNC | GPLE_PREDICT_FULL, y_extra, nullptr, nullptr, nullptr, &ps);
 			if (st == GPLE_OK) st = gple_complex_fit_get_scalars(fit, &sc);
 			gple_complex_fit_release(fit);
 			GPLE_TRY(st);

@@ -42,10 +42,12 @@ extern "C" {
 #define GPLE_CALC_DERIVATIVE 0x4u
 /* Array arguments of this call are device pointers. */
 #define GPLE_IO_DEVICE 0x100u
-/* *_predict: contract every test row.  By default a real-kernel predict skips the variance contraction for 128-row blocks of
- * test points whose K* rows are all so small (|k*|^2 < 2^-56 sf^2 sn^2 k(x*,x*)) that k(x*,x*) - k* K^-1 k*^T rounds to
- * k(x*,x*) whatever the contraction returns — grid points far from every training point.  The outputs are bit-identical
- * either way; the flag exists for measurements that want the full contraction timed. */
+/* *_predict: contract every test row.  By default a predict first sums K*^2 per test row (the generation's arithmetic without its
+ * HBM write), then generates K* and contracts only the rows with |k*|^2 >= 2^-56 sf^2 sn^2 k(x*,x*) (complex: half that): for the
+ * others k(x*,x*) - k* K^-1 k*^T rounds to k(x*,x*) whatever the contraction returns — grid points far from every training
+ * point, most of a phase-space grid.  The outputs are bit-identical either way.  Pass the flag for measurements that want the
+ * full contraction timed, and for test points known to lie on the data, where nothing can be skipped and the extra pass costs
+ * 2-13 % (gple_predict_batch, the step loop and the objective evaluations do that themselves). */
 #define GPLE_PREDICT_FULL 0x200u
 
 #define GPLE_REAL_NPARAM 4    /* KernelBase::NumTotalParameters        kernel.h:33          */
