@@ -204,8 +204,10 @@ def main():
     rows = 5 if cplx else 3
     alloc = lambda Cc, per: torch.zeros(Cc, per, dtype=torch.float64, device="cuda")
     # by_element: a rank that owns a whole element predicts the whole grid; nothing is gathered
-    shard = parallel.GridShardedStep(M, rows, alloc, via_host=args.backend == "gloo", shard=not by_element)
+    # --prune on several GPUs: block-cyclic shares, or one rank would hold all the live rows of the grid
+    shard = parallel.GridShardedStep(M, rows, alloc, via_host=args.backend == "gloo", shard=not by_element, cyclic=args.prune and not cplx)
     lo, hi = shard.lo, shard.hi
+    dgrid_mine = dgrid_all[shard.idx.to(dgrid_all.device)].contiguous() if shard.cyclic else None
 
     def fit():
         h = C.c_void_p()
@@ -221,7 +223,8 @@ def main():
         # complex outputs are interleaved (re, im) pairs: rows 0-1 / 3-4 of `out` viewed as one buffer of 2 * per doubles
         o_mean, o_var, o_cut = (out[0:2], out[2], out[3:5]) if cplx else (out[0], out[1], out[2])
         fn = api.lib.gple_complex_predict if cplx else api.lib.gple_real_predict
-        st = fn(api.ctx, h, dp(dgrid_all[lo:hi]), hi - lo, c.IO_DEVICE | predict_mode["flag"], None, dp(o_mean), dp(o_var), dp(o_cut), C.byref(ps))
+        pts, n = (dgrid_mine, len(dgrid_mine)) if hi is None else (dgrid_all[lo:hi], hi - lo)  # hi is None: cyclic share (lo = its indices)
+        st = fn(api.ctx, h, dp(pts), n, c.IO_DEVICE | predict_mode["flag"], None, dp(o_mean), dp(o_var), dp(o_cut), C.byref(ps))
         if st != 0:
             raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
 

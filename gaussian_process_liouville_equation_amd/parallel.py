@@ -50,6 +50,16 @@ def sharded_predict(predict_slice, grid, group=None):
     return allgather_rows(local, M, group)
 
 
+def cyclic_indices(M, rank, world, block=128):
+    """Grid rows of `rank` under the block-cyclic deal (block b of `block` points -> rank b % world) and the padded share length
+    every rank allocates.  What the C-ABI's gple_*_predict_sharded uses: with far-row pruning the live blocks of a phase-space
+    grid sit in one corner of it, and contiguous slices would hold anything between all and none of them."""
+    nblocks = (M + block - 1) // block
+    per = ((nblocks + world - 1) // world) * block
+    i = torch.arange(M)
+    return i[(i // block) % world == rank], per
+
+
 class GridShardedStep:
     """One fit + grid-predict step with the grid split over the ranks — the step `bench.py --gpus N` times and
     tests/test_distributed_gloo.py drives on CPU (same code, different backends plugged in).
@@ -59,16 +69,32 @@ class GridShardedStep:
     `local` is this rank's (C, per) buffer, allocated once by `alloc(C, per)`; `via_host` gathers through host memory (gloo
     rehearsal with device tensors)."""
 
-    def __init__(self, M, C, alloc, group=None, via_host=False, shard=True):
+    def __init__(self, M, C, alloc, group=None, via_host=False, shard=True, cyclic=False):
         # shard=False: this rank owns a whole element and predicts the whole grid itself (nothing is gathered)
+        # cyclic=True: block-cyclic shares (cyclic_indices) instead of contiguous slices; predict_slice then receives this rank's
+        # index tensor instead of (lo, hi): predict_slice(h, idx, None, out) fills out[:, :len(idx)]
         self.world = dist.get_world_size(group) if (shard and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if (shard and dist.is_initialized()) else 0
-        self.M, self.group, self.via_host = M, group, via_host
+        self.M, self.group, self.via_host, self.cyclic = M, group, via_host, cyclic and self.world > 1
         self.lo, self.hi, self.per = shard_bounds(M, self.rank, self.world)
+        if self.cyclic:
+            self.idx, self.per = cyclic_indices(M, self.rank, self.world)
+            self.all_idx = [cyclic_indices(M, r, self.world)[0] for r in range(self.world)]
         self.local = alloc(C, self.per)
 
     def run(self, fit, predict_slice):
         h = fit()
+        if self.cyclic:
+            predict_slice(h, self.idx, None, self.local)
+            loc = self.local.cpu() if self.via_host else self.local
+            C, per = loc.shape
+            out = torch.empty(self.world * C, per, dtype=loc.dtype, device=loc.device)
+            dist.all_gather_into_tensor(out, loc.contiguous(), group=self.group)
+            out = out.view(self.world, C, per)
+            full = torch.empty(C, self.M, dtype=loc.dtype, device=loc.device)
+            for r, idx in enumerate(self.all_idx):
+                full[:, idx.to(loc.device)] = out[r, :, :len(idx)]
+            return h, full.to(self.local.device)
         predict_slice(h, self.lo, self.hi, self.local)
         if self.world == 1:
             return h, self.local[:, :self.M]
