@@ -343,8 +343,8 @@ def main():
         live, seen = api.prune_stats(reset=True)
         result["pruned"] = {"ms_per_step": round(1e3 * t_pruned, 4), "blocks_contracted": live // nrep, "blocks_seen": seen // nrep,
                             "bit_identical_to_full": bool(torch.equal(full_out, last["full"])),
-                            "note": "the library's default predict: 128-row blocks of grid points whose K* rows satisfy |k*|^2 < 2^-56 sf^2 sn^2 k(x*,x*) "
-                                    "are not contracted (k(x*,x*) - k* K^-1 k*^T rounds to k(x*,x*) either way); not the judged value"}
+                            "note": "the library's default predict: grid rows with |k*|^2 < 2^-56 sf^2 sn^2 k(x*,x*) are not contracted "
+                                    "(k(x*,x*) - k* K^-1 k*^T rounds to k(x*,x*) either way; blocks_* count live / all rows in units of 128); not the judged value"}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(args.workload, N, G, kernel, X, y, grid, theta)
     if rank == 0:

@@ -348,7 +348,7 @@ class Api:
         return last.value, total.value, count.value
 
     def prune_stats(self, reset=False):
-        """(contracted, seen) 128-row blocks of test points in the row-norm kernels since creation / the last reset."""
+        """(contracted, seen) test rows of the pruned predicts in units of 128 rows since creation / the last reset."""
         a, b = C.c_ulonglong(), C.c_ulonglong()
         self._check(self.lib.gple_ctx_get_prune_stats(self.ctx, C.byref(a), C.byref(b), int(bool(reset))))
         return a.value, b.value

@@ -147,8 +147,8 @@ namespace gple
 		double* q;       // m_rows: || T k*_m ||^2
 		double* mu;      // m_rows: k*_m . v
 		SEParamSet ps;
-		double prune_thr;                // > 0: 128-row blocks whose rows all have |k*|^2 below it are not contracted (gple_predict.hip, Prune)
-		unsigned long long* prune_stats; // device, optional: [0] += live blocks, [1] += blocks seen
+		double prune_thr;                // > 0: rows with |k*|^2 below it are not contracted (gple_predict.hip, Prune)
+		unsigned long long* prune_stats; // device, 4 words: [0] += ceil(live rows / 128), [1] += rows / 128, [2] work-queue counter, [3] live-row count
 	};
 	// Rolling K* scratch of the predict path (HBM): bounded so that M x N never has to exist at once.
 	constexpr size_t PREDICT_SCRATCH_BYTES = size_t(4) << 30;

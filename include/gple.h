@@ -143,8 +143,8 @@ int gple_ctx_enable_timing(gple_ctx* ctx, int on);
 /* Synchronises the stream, then: last = milliseconds of the most recent interval; total / count = accumulated since
  * enable (any may be NULL). */
 int gple_ctx_get_timing(gple_ctx* ctx, gple_timer which, double* last_ms, double* total_ms, long* count);
-/* Synchronises the stream, then: 128-row blocks of test points the row-norm kernels contracted / saw since the context was
- * created or since the last call with reset != 0 (see GPLE_PREDICT_FULL). */
+/* Synchronises the stream, then: test rows the pruned predicts contracted / saw, in units of 128 rows (ceil of the live rows of
+ * each predict), since the context was created or since the last call with reset != 0 (see GPLE_PREDICT_FULL). */
 int gple_ctx_get_prune_stats(gple_ctx* ctx, unsigned long long* contracted_blocks, unsigned long long* seen_blocks, int reset);
 
 /* ---- KernelBase (kernel.h:29-106, kernel.cpp:8-242) ---------------------------------------------- */
