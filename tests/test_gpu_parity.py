@@ -521,3 +521,29 @@ def test_far_row_pruning_complex_is_bit_identical(gpu):
     for k in ("prediction", "variance", "cutoff"):
         assert np.array_equal(full[k], pruned[k]), k
     fit.release()
+
+
+def test_far_row_pruning_edge_cases(gpu):
+    """the compacted list longer than one K* chunk (all rows live, 135 000 of them at N = 4096: two chunks of the list), and
+    the empty list (every row dead): both bit-identical to the full contraction"""
+    from tests.test_gpu_configs import config_inputs, THETA_R
+    N = 4096
+    X, y, _, _ = config_inputs(N, 8, 1)
+    fit = gpu.real_fit(THETA_R, X, y, 0)
+    rng = np.random.default_rng(11)
+    near = X[rng.integers(0, N, 135000)] + rng.normal(0, 0.2, (135000, 2))
+    gpu.prune_stats(reset=True)
+    a = gpu.real_predict(fit, near, want=("variance", "cutoff"))
+    live, seen = gpu.prune_stats(reset=True)
+    assert live == seen == (135000 + 127) // 128
+    b = gpu.real_predict(fit, near, flags=c.PREDICT_FULL, want=("variance", "cutoff"))
+    assert np.array_equal(a["variance"], b["variance"]) and np.array_equal(a["cutoff"], b["cutoff"])
+    far = np.stack([np.linspace(30.0, 60.0, 20000), np.linspace(-40.0, -10.0, 20000)], 1)
+    a = gpu.real_predict(fit, far)
+    live, seen = gpu.prune_stats(reset=True)
+    assert live == 0 and seen == (20000 + 127) // 128
+    b = gpu.real_predict(fit, far, flags=c.PREDICT_FULL)
+    for k in ("prediction", "variance", "cutoff"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.all(a["variance"] == THETA_R[0] ** 2 * (1 + THETA_R[3] ** 2))
+    fit.release()
