@@ -19,6 +19,7 @@
 #include <limits>
 #include <new>
 
+#include "gple_debug.h"
 #include "gple_kernels.h"
 
 using namespace gple;
@@ -2155,7 +2156,7 @@ extern "C"
 		return nlml_predict_impl(ctx, x, 5, X, y, N, Xs, M, flags, mean);
 	}
 
-	/* not part of include/gple.h: instrumented launch of the diagonal-block kernel for probes/diag_probe.py.
+	/* gple_debug.h (not part of include/gple.h): instrumented launch of the diagonal-block kernel for probes/diag_probe.py.
 	 * A: 64 x 64 column-major SPD block (host); T out: inv(chol(A)) (host); stamps: 16 cycle-counter values (host). */
 	int gple_debug_potrf_diag(gple_ctx* ctx, const double* A, double* T, long long* stamps, int reps, float* ms_per_launch)
 	{
@@ -2187,7 +2188,7 @@ extern "C"
 		return GPLE_OK;
 	}
 
-	/* not part of include/gple.h: one product of the fp64 MFMA GEMM family on host operands, for tests/test_gpu_gemm.py.
+	/* gple_debug.h (not part of include/gple.h): one product of the fp64 MFMA GEMM family on host operands, for tests/test_gpu_gemm.py.
 	 * C(m,n) = alpha sum_k A(m,k) B(n,k) + beta C(m,n); layouts and k-ranges as GemmDesc (csrc/gple_internal.h);
 	 * tile = 32 | 64 | 128 | 0 (the library's own choice for this shape). */
 	int gple_debug_gemm(gple_ctx* ctx, const double* A, long lda, int a_kmajor, const double* B, long ldb, int b_kmajor, double* C, long ldc,

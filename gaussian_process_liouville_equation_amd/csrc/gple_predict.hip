@@ -242,10 +242,6 @@ namespace gple
 				if (live) list[p] = row;
 			}
 		}
-		// q[row] = sum of the VG planes at the row's list position (fixed order), 0 for a dead row; statistics
-		__global__ void __launch_bounds__(256) scatter_q_kernel(const double* __restrict__ qpart, long qstride, const int* __restrict__ pos, int m_rows,
-			double* __restrict__ q, const int* __restrict__ n_live, unsigned long long* __restrict__ stats);
-
 		// A row's squared norm is the sum over the N-tiles of T; which workgroup adds which tiles depends on how many groups the launch
 		// splits a row block into (rownorm_split: by the number of row blocks).  So that the VALUE does not depend on that choice,
 		// the tiles are dealt out to VG fixed "virtual groups" in snake order (tile jt costs jt + 1 units), every virtual group
@@ -258,6 +254,7 @@ namespace gple
 			const int p = v % (2 * G);
 			return p < G ? p : 2 * G - 1 - p;
 		}
+		// q[row] = sum of the VG planes at the row's list position (fixed order), 0 for a dead row; statistics
 		__global__ void __launch_bounds__(256) scatter_q_kernel(const double* __restrict__ qpart, long qstride, const int* __restrict__ pos, int m_rows,
 			double* __restrict__ q, const int* __restrict__ n_live, unsigned long long* __restrict__ stats)
 		{
