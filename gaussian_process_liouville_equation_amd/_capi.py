@@ -173,7 +173,7 @@ GPLE_SYMBOLS = [
     "real_gram", "complex_gram", "cutoff_factor", "predict_batch", "shard_bounds", "set_allgather_function", "real_predict_sharded", "complex_predict_sharded",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
-    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "minimize_neldermead", "objective_minimize_neldermead", "minimize_auglag_eq", "pes_adiabatic", "evolve", "markov_chain", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
+    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "minimize_neldermead", "objective_minimize_neldermead", "minimize_auglag_eq", "pes_adiabatic", "evolve", "markov_chain", "markov_chain_trace", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
 ]
 
 
@@ -427,10 +427,17 @@ class Api:
         self._check(self.lib.gple_evolve(self.ctx, self._elements(fits), int(model), float(mass), float(dt), pts, 0))
         return {e: (rs[k], rhos[k]) for k, e in enumerate(order)}
 
-    def markov_chain(self, fit, num_steps, max_displacement, seed, r):
-        """Metropolis chains of all walkers on |cut-off prediction| of `fit`: (last points (n,2), acceptance ratio (n,))"""
+    def markov_chain(self, fit, num_steps, max_displacement, seed, r, want_chain=False):
+        """Metropolis chains of all walkers on |cut-off prediction| of `fit`: (last points (n,2), acceptance ratio (n,)); with
+        want_chain also the whole chains (num_steps + 1, n, 2)"""
         r = np.ascontiguousarray(np.asarray(r, dtype=np.float64).reshape(-1, 2)).copy()
         acc = np.empty(len(r))
+        if want_chain:
+            chain = np.empty((int(num_steps) + 1, len(r), 2))
+            self.lib.gple_markov_chain_trace.argtypes = [C.c_void_p, C.POINTER(Element), C.c_size_t, C.c_double, C.c_ulonglong, _dp, C.c_size_t, _dp, _dp]
+            self._check(self.lib.gple_markov_chain_trace(self.ctx, self._elements([fit]), int(num_steps), float(max_displacement), int(seed), _ptr(r), len(r),
+                                                         _ptr(acc), _ptr(chain)))
+            return r, acc, chain
         self.lib.gple_markov_chain.argtypes = [C.c_void_p, C.POINTER(Element), C.c_size_t, C.c_double, C.c_ulonglong, _dp, C.c_size_t, _dp]
         self._check(self.lib.gple_markov_chain(self.ctx, self._elements([fit]), int(num_steps), float(max_displacement), int(seed), _ptr(r), len(r), _ptr(acc)))
         return r, acc

@@ -1868,8 +1868,8 @@ extern "C"
 		return GPLE_OK;
 	}
 
-	int gple_markov_chain(gple_ctx* ctx, const gple_element* element, size_t num_steps, double max_displacement, unsigned long long seed, double* r,
-		size_t n, double* accept_ratio)
+	static int markov_chain_impl(gple_ctx* ctx, const gple_element* element, size_t num_steps, double max_displacement, unsigned long long seed, double* r,
+		size_t n, double* accept_ratio, double* chain)
 	{
 		if (!ctx || !element || (n && !r) || n > (1u << 28) || (element->real && element->cplx)) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
@@ -1877,10 +1877,11 @@ extern "C"
 		hipStream_t st = ctx->stream;
 		const int ni = static_cast<int>(n), cplx = element->cplx ? 1 : 0;
 		const bool has_fit = element->real || element->cplx;
-		Scratch rd(ctx), rp(ctx), pred(ctx), weight(ctx), acc(ctx);
+		Scratch rd(ctx), rp(ctx), pred(ctx), weight(ctx), acc(ctx), trace(ctx);
 		{
 			std::lock_guard<std::mutex> lk(ctx->call_mu);
 			GPLE_HIP(ctx, hipSetDevice(ctx->device));
+			if (chain) GPLE_HIP(ctx, trace.get((num_steps + 1) * 2 * n)); // the whole chains, [step][walker][2]
 			GPLE_HIP(ctx, rd.get(2 * n));
 			GPLE_HIP(ctx, rp.get(2 * n));
 			GPLE_HIP(ctx, pred.get(2 * n));
@@ -1888,6 +1889,7 @@ extern "C"
 			GPLE_HIP(ctx, acc.get(n / 2 + 1));
 			GPLE_HIP(ctx, copy_in(st, rd.p, r, 2 * n, false));
 			GPLE_HIP(ctx, hipMemsetAsync(acc.p, 0, (n / 2 + 1) * 8, st));
+			if (chain) GPLE_HIP(ctx, hipMemcpyAsync(trace.p, rd.p, 2 * n * 8, hipMemcpyDeviceToDevice, st));
 		}
 		GPLE_TRY(predict_element_cutoff(ctx, *element, rd.p, n, pred.p));
 		{
@@ -1904,15 +1906,29 @@ extern "C"
 			std::lock_guard<std::mutex> lk(ctx->call_mu);
 			GPLE_HIP(ctx, launch_mc_accept(st, rd.p, rp.p, has_fit ? pred.p : nullptr, cplx, ni, static_cast<unsigned>(step), seed, weight.p,
 							  reinterpret_cast<unsigned*>(acc.p)));
+			if (chain) GPLE_HIP(ctx, hipMemcpyAsync(trace.p + (step + 1) * 2 * n, rd.p, 2 * n * 8, hipMemcpyDeviceToDevice, st));
 		}
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, copy_out(st, r, rd.p, 2 * n, false));
+		if (chain) GPLE_HIP(ctx, copy_out(st, chain, trace.p, (num_steps + 1) * 2 * n, false));
 		std::vector<unsigned> counts(accept_ratio ? n : 0);
 		if (accept_ratio) GPLE_HIP(ctx, hipMemcpyAsync(counts.data(), acc.p, n * sizeof(unsigned), hipMemcpyDeviceToHost, st));
 		GPLE_HIP(ctx, hipStreamSynchronize(st));
 		if (accept_ratio)
 			for (size_t i = 0; i < n; ++i) accept_ratio[i] = num_steps ? static_cast<double>(counts[i]) / static_cast<double>(num_steps) : 0.0;
 		return GPLE_OK;
+	}
+
+	int gple_markov_chain(gple_ctx* ctx, const gple_element* element, size_t num_steps, double max_displacement, unsigned long long seed, double* r,
+		size_t n, double* accept_ratio)
+	{
+		return markov_chain_impl(ctx, element, num_steps, max_displacement, seed, r, n, accept_ratio, nullptr);
+	}
+	int gple_markov_chain_trace(gple_ctx* ctx, const gple_element* element, size_t num_steps, double max_displacement, unsigned long long seed,
+		double* r, size_t n, double* accept_ratio, double* chain)
+	{
+		if (!chain) return GPLE_ERR_BAD_ARG;
+		return markov_chain_impl(ctx, element, num_steps, max_displacement, seed, r, n, accept_ratio, chain);
 	}
 
 	// loose_function (opt.cpp:441-482).  io = 0: host pointers; io = GPLE_IO_DEVICE: everything but x / value / grad is resident

@@ -312,6 +312,10 @@ int gple_evolve(gple_ctx* ctx, const gple_element elements[3], int pes_model, do
  * between threads, mc.cpp:17: no stream of it is reproducible).  Host pointers. */
 int gple_markov_chain(gple_ctx* ctx, const gple_element* element, size_t num_steps, double max_displacement, unsigned long long seed,
 	double* r, size_t n, double* accept_ratio);
+/* The same with every chain recorded (the WholeChain of mc.cpp:118-165, what autocorrelation_optimize_steps mc.cpp:167-285 looks at):
+ * chain[(step * n + walker) * 2 + d], step = 0 (start point) .. num_steps. */
+int gple_markov_chain_trace(gple_ctx* ctx, const gple_element* element, size_t num_steps, double max_displacement,
+	unsigned long long seed, double* r, size_t n, double* accept_ratio, double* chain);
 
 /* ---- negative_log_marginal_likelihood / predict (test/gpr.cpp:499-532, 654-706) -------------------- */
 /* Kernel = w_d^2 * Diag + w_g^2 * GaussianARD(weights), x = (w_d, w_g, a_x, a_p) with `a` the diagonal ARD

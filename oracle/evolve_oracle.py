@@ -228,14 +228,15 @@ def philox_uniform(walker, step, seed):
     return to_unit(out[0][..., 0], out[0][..., 1]), to_unit(out[0][..., 2], out[0][..., 3]), to_unit(out[1][..., 0], out[1][..., 1])
 
 
-def generate_markov_chain(num_steps, distribution, max_displacement, i, j, r, seed):
+def generate_markov_chain(num_steps, distribution, max_displacement, i, j, r, seed, want_chain=False):
     """mc.cpp:118-165 for all walkers at once (one batched distribution call per Monte-Carlo step); returns the last points
-    and the acceptance ratio per walker.  Uniform displacement in [-d, d) per dimension, accept when the new |rho| is larger
-    or with probability new / old."""
+    and the acceptance ratio per walker (and, on request, the whole chains (num_steps + 1, n, 2)).  Uniform displacement in
+    [-d, d) per dimension, accept when the new |rho| is larger or with probability new / old."""
     r = np.asarray(r, dtype=float).copy()
     walkers = np.arange(len(r))
     weight_old = np.abs(distribution(r, i, j))
     acc = np.zeros(len(r))
+    chain = [r.copy()]
     for step in range(num_steps):
         u0, u1, u2 = philox_uniform(walkers, step, seed)
         r_new = r + np.stack([(2.0 * u0 - 1.0) * max_displacement, (2.0 * u1 - 1.0) * max_displacement], axis=1)
@@ -245,4 +246,8 @@ def generate_markov_chain(num_steps, distribution, max_displacement, i, j, r, se
         r = np.where(accept[:, None], r_new, r)
         weight_old = np.where(accept, weight_new, weight_old)
         acc += accept
+        if want_chain:
+            chain.append(r.copy())
+    if want_chain:
+        return r, acc / max(1, num_steps), np.stack(chain)
     return r, acc / max(1, num_steps)

@@ -150,3 +150,36 @@ def test_average_line_on_the_device_against_oracle(gpu, oracle):
     assert a.shape == b.shape == (34,)
     both = ~(np.isnan(a) | np.isnan(b))
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.allclose(a[both], b[both], rtol=2e-5, atol=1e-9)  # %g keeps 6 digits
+
+
+def test_monte_carlo_selection_on_the_device(gpu, oracle):
+    """steploop.monte_carlo_selection (mc.cpp:333-403: displacement and chain-length tuning, then the walk) on the device chains
+    against the same host logic driven by the oracle's chains and predictor: same tuned parameters; the re-selected points agree
+    wherever no accept decision sat within rounding of its random number; densities are the fit's cut-off prediction there."""
+    from gaussian_process_liouville_equation_amd import steploop as S
+    dens = _case(96, 31)
+    dens = {(0, 0): dens[(0, 0)], (1, 0): (np.zeros((0, 2)), np.zeros(0, dtype=complex)), (1, 1): (np.zeros((0, 2)), np.zeros(0, dtype=complex))}
+    params = {(0, 0): TH, (1, 0): THC, (1, 1): TH}
+    kg = K.TrainingKernels(params, K.construct_training_sets(dens), True, True, False, api=gpu)
+    mcg = {e: S.MCParameters() for e in dens}
+    # shorter tuning runs than the reference's 1000 / 2000 steps keep the oracle side of this test at seconds
+    orig = (S.acceptance_optimize_displacement.__defaults__, S.autocorrelation_optimize_steps.__defaults__)
+    S.acceptance_optimize_displacement.__defaults__, S.autocorrelation_optimize_steps.__defaults__ = (120,), (160,)
+    try:
+        new = S.monte_carlo_selection(dens, mcg, kg, seed=2024)
+        X, rho = dens[(0, 0)]
+        fo = oracle.real_fit(TH, X, rho, 0)
+        dist = lambda pts, i=0, j=0: oracle.real_predict(fo, pts, want=("cutoff",))["cutoff"]
+        chain = lambda n, d, r, seed, want_chain=False: E.generate_markov_chain(n, dist, d, 0, 0, r, seed, want_chain)
+        mco = S.MCParameters()
+        ro, rhoo = S.element_monte_carlo((X, rho), mco, chain, lambda r: dist(r), S._Seeds(2024))
+    finally:
+        S.acceptance_optimize_displacement.__defaults__, S.autocorrelation_optimize_steps.__defaults__ = orig
+    assert mcg[(0, 0)].get_max_displacement() == mco.get_max_displacement()
+    assert abs(mcg[(0, 0)].get_num_MC_steps() - mco.get_num_MC_steps()) <= 2
+    rg, rhog = new[(0, 0)]
+    assert rg.shape == X.shape and len(new[(1, 0)][0]) == 0
+    if mcg[(0, 0)].get_num_MC_steps() == mco.get_num_MC_steps():
+        assert (np.abs(rg - ro).max(axis=1) <= 1e-10).mean() >= 0.9
+    fg = kg(0)._fit
+    assert np.abs(rhog.real - gpu.real_predict(fg, rg, want=("cutoff",))["cutoff"]).max() <= 1e-12 * np.abs(rhog).max() and np.all(rhog.imag == 0)

@@ -67,3 +67,44 @@ def test_metropolis_samples_the_target():
     assert abs(r[:, 0].std() - 0.7) < 0.06 and abs(r[:, 1].std() - 0.5) < 0.05
     _, acc_big = E.generate_markov_chain(60, target, 3.0, 0, 0, start, seed=42)
     assert 0.15 < acc.mean() < 0.9 and acc_big.mean() < acc.mean()
+
+
+def test_chain_autocorrelation_against_the_double_loop():
+    """steploop.chain_autocorrelation (FFT) == the literal double loop of mc.cpp:205-226"""
+    from gaussian_process_liouville_equation_amd import steploop
+    rng = np.random.default_rng(2)
+    whole = np.cumsum(rng.normal(size=(41, 5, 2)), axis=0)  # 5 random walks of 41 points
+    got = steploop.chain_autocorrelation(whole)
+    n = whole.shape[0]
+    ref = np.zeros(n // 2)
+    for w in range(whole.shape[1]):
+        ave = whole[:, w].mean(axis=0)
+        for j in range(n // 2):
+            ref[j] += sum(np.dot(whole[i, w] - ave, whole[i + j, w] - ave) for i in range(n - j)) / (n - j)
+    ref /= whole.shape[1]
+    assert len(got) == n // 2 and np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_monte_carlo_tuning_on_an_analytic_density():
+    """mc.cpp:167-372 on a Gaussian density (no GP involved: distribution = the exact density): the chosen displacement is the largest
+    of the table whose acceptance lies inside the band, the chain length is a lag inside the measured window, and
+    element_monte_carlo returns points with the density evaluated there."""
+    from gaussian_process_liouville_equation_amd import steploop as S
+    rng = np.random.default_rng(3)
+    sig = np.array([0.7086, 0.7056])
+    rho = lambda r: np.exp(-0.5 * (((r - [-10.0, 14.112]) / sig) ** 2).sum(axis=1)) / (2 * np.pi * sig.prod())
+    dist = lambda r, i, j: rho(r).astype(complex)
+    chain = lambda n, d, r, seed, want_chain=False: E.generate_markov_chain(n, dist, d, 0, 0, r, seed, want_chain)
+    r0 = np.array([-10.0, 14.112]) + sig * rng.normal(size=(60, 2))
+    mc, seeds = S.MCParameters(), S._Seeds(99)
+    S.acceptance_optimize_displacement(mc, chain, r0, seeds, MaxNOMC=300)
+    d = mc.get_max_displacement()
+    ratio = lambda dd: float(np.mean(chain(300, dd, r0, 12345)[1]))
+    assert d in S.PossibleDisplacement and S.MinAcceptRatio < ratio(d) < S.MaxAcceptRatio
+    bigger = [x for x in S.PossibleDisplacement if x > d]
+    assert all(not (S.MinAcceptRatio < ratio(x) < S.MaxAcceptRatio) or abs(ratio(x) - S.MinAcceptRatio) < 0.03 for x in bigger)  # (other seed: band edge)
+    S.autocorrelation_optimize_steps(mc, chain, r0, seeds, MaxNOMC=400)
+    assert 1 <= mc.get_num_MC_steps() < 200
+    r1, rho1 = S.element_monte_carlo((r0, rho(r0).astype(complex)), S.MCParameters(), lambda n, dd, r, s, w=False: chain(min(n, 300), dd, r, s, w),
+                                     lambda r: rho(r), S._Seeds(5))
+    assert r1.shape == r0.shape and np.allclose(rho1, rho(r1)) and np.abs(r1 - r0).max() > 0
