@@ -15,6 +15,7 @@ CALC_ERROR = 0x1
 CALC_AVERAGE = 0x2
 CALC_DERIVATIVE = 0x4
 IO_DEVICE = 0x100
+EVOLVE_NEW_POINTS = 0x400  # gple_evolve: new_point_predict instead of a tick
 PREDICT_FULL = 0x200  # contract every test row (default: far rows whose contraction cannot move the variance are skipped)
 
 # gple_real_array / gple_complex_array
@@ -414,9 +415,10 @@ class Api:
         self._check(self.lib.gple_pes_adiabatic(self.ctx, int(model), _ptr(x), len(x), 0, _ptr(out)))
         return out.reshape(-1, 6)
 
-    def evolve(self, fits, model, mass, dt, density):
+    def evolve(self, fits, model, mass, dt, density, new_points=False):
         """one tick of evolve(): fits = [fit(0,0) | None, fit(1,0) | None, fit(1,1) | None]; density = {(i, j): (r (n,2), rho (n,))}
-        -> the same structure one tick later"""
+        -> the same structure one tick later.  new_points: new_point_predict (evolve.cpp:425-443) at the given points instead — they
+        stay where they are and rho becomes what the back-propagation predicts there from the fits alone (0 where uncoupled)."""
         order = [(0, 0), (1, 0), (1, 1)]
         rs = [np.ascontiguousarray(np.asarray(density[e][0], dtype=np.float64).reshape(-1, 2)).copy() for e in order]
         rhos = [np.ascontiguousarray(np.asarray(density[e][1], dtype=np.complex128)).copy() for e in order]
@@ -424,7 +426,7 @@ class Api:
         for k in range(3):
             pts[k].r, pts[k].rho, pts[k].n = _ptr(rs[k]), _ptr(rhos[k].view(np.float64)), len(rs[k])
         self.lib.gple_evolve.argtypes = [C.c_void_p, C.POINTER(Element), C.c_int, C.c_double, C.c_double, C.POINTER(Points), C.c_uint]
-        self._check(self.lib.gple_evolve(self.ctx, self._elements(fits), int(model), float(mass), float(dt), pts, 0))
+        self._check(self.lib.gple_evolve(self.ctx, self._elements(fits), int(model), float(mass), float(dt), pts, EVOLVE_NEW_POINTS if new_points else 0))
         return {e: (rs[k], rhos[k]) for k, e in enumerate(order)}
 
     def markov_chain(self, fit, num_steps, max_displacement, seed, r, want_chain=False):

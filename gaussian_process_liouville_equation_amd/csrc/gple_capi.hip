@@ -1823,7 +1823,8 @@ extern "C"
 		const bool dev = flags & GPLE_IO_DEVICE;
 		long qoff[3][3], qlen[3];
 		int off[3];
-		evolve_layout(n, qoff, qlen, off);
+		const int new_points = (flags & GPLE_EVOLVE_NEW_POINTS) ? 1 : 0;
+		evolve_layout(n, qoff, qlen, off, new_points);
 		hipStream_t st = ctx->stream;
 		Scratch r_old(ctx), rho_old(ctx), r_new(ctx), rho_new(ctx), cpl(ctx), q0(ctx), q1(ctx), q2(ctx), p0(ctx), p1(ctx), p2(ctx);
 		Scratch* q[3] = {&q0, &q1, &q2};
@@ -1845,7 +1846,7 @@ extern "C"
 				GPLE_HIP(ctx, copy_in(st, rho_old.p + 2 * off[e], density[e].rho, 2 * density[e].n, dev));
 			}
 			double* const qp[3] = {q0.p, q1.p, q2.p};
-			GPLE_HIP(ctx, launch_evolve_prepare(st, r_old.p, n, mass, dt, pes_model, r_new.p, reinterpret_cast<unsigned char*>(cpl.p), qp));
+			GPLE_HIP(ctx, launch_evolve_prepare(st, r_old.p, n, mass, dt, pes_model, r_new.p, reinterpret_cast<unsigned char*>(cpl.p), qp, new_points));
 		}
 		// one batched predict per density-matrix element over everything that was back-propagated into it
 		const double* pred[3] = {nullptr, nullptr, nullptr};
@@ -1858,7 +1859,7 @@ extern "C"
 		}
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
-		GPLE_HIP(ctx, launch_evolve_combine(st, r_old.p, r_new.p, rho_old.p, reinterpret_cast<const unsigned char*>(cpl.p), n, mass, dt, pes_model, pred, rho_new.p));
+		GPLE_HIP(ctx, launch_evolve_combine(st, r_old.p, r_new.p, rho_old.p, reinterpret_cast<const unsigned char*>(cpl.p), n, mass, dt, pes_model, pred, rho_new.p, new_points));
 		for (int e = 0; e < 3; ++e)
 		{
 			GPLE_HIP(ctx, copy_out(st, density[e].r, r_new.p + 2 * off[e], 2 * density[e].n, dev));

@@ -148,15 +148,18 @@ namespace gple
 		// concatenated point arrays.  Target element e receives from source s three rows per point (branches -1, 0, +1), except
 		// from itself: the 0-branch is the exact density (evolve.cpp:309-313), so two rows per point — and the first of the two
 		// carries the un-propagated point instead when the point is not coupled (the adiabatic branch, evolve.cpp:411-418).
+		// new_points (new_point_predict, evolve.cpp:425-443): the points are NOT propagated, there is no exact density — the element
+		// itself is predicted on its 0-branch like every other slot (three rows per point everywhere) — and an uncoupled point gets 0.
 		struct EvolveLayout
 		{
 			int n[3], off[3];
 			long qoff[3][3]; // row of the first query of source s inside target e's list: qoff[e][s]
 			long qlen[3];
+			int new_points;
 		};
 		__device__ __forceinline__ long query_row(const EvolveLayout& L, int e, int s, int idx, int b)
 		{
-			if (e == s) return L.qoff[e][s] + 2L * idx + (b == 0 ? 0 : 1); // b in {0, 2}
+			if (e == s && !L.new_points) return L.qoff[e][s] + 2L * idx + (b == 0 ? 0 : 1); // b in {0, 2}
 			return L.qoff[e][s] + 3L * idx + b;
 		}
 
@@ -174,13 +177,16 @@ namespace gple
 			const double x0 = r[2 * t], p0 = r[2 * t + 1];
 			const bool cpl = is_coupling(x0, p0, mass, dt, model);
 			double xn = x0, pn = p0;
-			if (cpl)
+			if (!L.new_points)
 			{
-				adiabatic_evolve(xn, pn, mass, dt / 2.0, 1.0, row, col, model);
-				adiabatic_evolve(xn, pn, mass, dt / 2.0, 1.0, row, col, model);
+				if (cpl)
+				{
+					adiabatic_evolve(xn, pn, mass, dt / 2.0, 1.0, row, col, model);
+					adiabatic_evolve(xn, pn, mass, dt / 2.0, 1.0, row, col, model);
+				}
+				else
+					adiabatic_evolve(xn, pn, mass, dt, 1.0, row, col, model);
 			}
-			else
-				adiabatic_evolve(xn, pn, mass, dt, 1.0, row, col, model);
 			r_new[2 * t] = xn, r_new[2 * t + 1] = pn;
 			coupled[t] = cpl ? 1 : 0;
 			const BackProp g = back_propagate(xn, pn, mass, dt, row, col, model);
@@ -190,7 +196,7 @@ namespace gple
 #pragma unroll
 				for (int b = 0; b < 3; ++b)
 				{
-					if (e == s && b == 1) continue; // the exact element on the 0-branch is not predicted
+					if (e == s && b == 1 && !L.new_points) continue; // the exact element on the 0-branch is not predicted
 					const long qr = query_row(L, e, s, idx, b);
 					const bool adiabatic_slot = !cpl && e == s && b == 0;
 					q[e][2 * qr] = adiabatic_slot ? x0 : g.x4[e][b];
@@ -217,6 +223,11 @@ namespace gple
 				const double* __restrict__ p = e == 0 ? pred0 : pred2;
 				return Cplx{p ? p[qr] : 0.0, 0.0};
 			};
+			if (!coupled[t] && L.new_points) // evolve.cpp:439-442
+			{
+				rho_new[2 * t] = 0.0, rho_new[2 * t + 1] = 0.0;
+				return;
+			}
 			if (!coupled[t])
 			{
 				// rho = distribution(r_old) * exp(-i omega0 dt), evolve.cpp:415
@@ -235,7 +246,7 @@ namespace gple
 			{
 				Cplx rp[3];
 #pragma unroll
-				for (int e = 0; e < 3; ++e) rp[e] = (e == s && b == 1) ? Cplx{rho_old[2 * t], rho_old[2 * t + 1]} : fetch(e, b);
+				for (int e = 0; e < 3; ++e) rp[e] = (e == s && b == 1 && !L.new_points) ? Cplx{rho_old[2 * t], rho_old[2 * t + 1]} : fetch(e, b);
 				rp[1] = cmul_phase(rp[1], omega01(g.x2, g.x4[1][b], 1.0, model) * dt / 2.0); // :327-329
 				offdiagonal_rotation(rp, g.x2, g.p2[b], mass, dt / 2.0, model);              // :331-337
 				if (b == 0) // branch -1, :341-344: the same value goes to all three elements
@@ -345,7 +356,7 @@ namespace gple
 		hipLaunchKernelGGL(pes_kernel, dim3((M + 255) / 256), dim3(256), 0, s, x, M, model, out6);
 		return hipGetLastError();
 	}
-	void evolve_layout(const int n[3], long qoff[3][3], long qlen[3], int off[3])
+	void evolve_layout(const int n[3], long qoff[3][3], long qlen[3], int off[3], int new_points)
 	{
 		off[0] = 0, off[1] = n[0], off[2] = n[0] + n[1];
 		for (int e = 0; e < 3; ++e)
@@ -354,16 +365,17 @@ namespace gple
 			for (int s = 0; s < 3; ++s)
 			{
 				qoff[e][s] = pos;
-				pos += static_cast<long>(e == s ? 2 : 3) * n[s];
+				pos += static_cast<long>(e == s && !new_points ? 2 : 3) * n[s];
 			}
 			qlen[e] = pos;
 		}
 	}
 	hipError_t launch_evolve_prepare(hipStream_t s, const double* r, const int n[3], double mass, double dt, int model, double* r_new,
-		unsigned char* coupled, double* const q[3])
+		unsigned char* coupled, double* const q[3], int new_points)
 	{
 		EvolveLayout L;
-		evolve_layout(n, L.qoff, L.qlen, L.off);
+		L.new_points = new_points;
+		evolve_layout(n, L.qoff, L.qlen, L.off, new_points);
 		for (int e = 0; e < 3; ++e) L.n[e] = n[e];
 		const int total = n[0] + n[1] + n[2];
 		if (total == 0) return hipSuccess;
@@ -371,10 +383,11 @@ namespace gple
 		return hipGetLastError();
 	}
 	hipError_t launch_evolve_combine(hipStream_t s, const double* r_old, const double* r_new, const double* rho_old, const unsigned char* coupled,
-		const int n[3], double mass, double dt, int model, const double* const pred[3], double* rho_new)
+		const int n[3], double mass, double dt, int model, const double* const pred[3], double* rho_new, int new_points)
 	{
 		EvolveLayout L;
-		evolve_layout(n, L.qoff, L.qlen, L.off);
+		L.new_points = new_points;
+		evolve_layout(n, L.qoff, L.qlen, L.off, new_points);
 		for (int e = 0; e < 3; ++e) L.n[e] = n[e];
 		const int total = n[0] + n[1] + n[2];
 		if (total == 0) return hipSuccess;

@@ -113,11 +113,11 @@ namespace gple
 	// ---- step loop around the GP (gple_evolve.hip): Tully models, MQCLE propagation, Metropolis ---------------------------------
 	hipError_t launch_pes(hipStream_t s, const double* x, int M, int model, double* out6);
 	// query-list layout of one tick: off[s] = first point of source element s, qoff[e][s] / qlen[e] = rows of target e's list
-	void evolve_layout(const int n[3], long qoff[3][3], long qlen[3], int off[3]);
+	void evolve_layout(const int n[3], long qoff[3][3], long qlen[3], int off[3], int new_points = 0);
 	hipError_t launch_evolve_prepare(hipStream_t s, const double* r, const int n[3], double mass, double dt, int model, double* r_new,
-		unsigned char* coupled, double* const q[3]);
+		unsigned char* coupled, double* const q[3], int new_points = 0);
 	hipError_t launch_evolve_combine(hipStream_t s, const double* r_old, const double* r_new, const double* rho_old, const unsigned char* coupled,
-		const int n[3], double mass, double dt, int model, const double* const pred[3], double* rho_new);
+		const int n[3], double mass, double dt, int model, const double* const pred[3], double* rho_new, int new_points = 0);
 	hipError_t launch_mc_propose(hipStream_t s, const double* r, int n, unsigned step, unsigned long long seed, double d, double* r_prop);
 	hipError_t launch_mc_weight(hipStream_t s, const double* pred, int is_complex, int n, double* weight);
 	hipError_t launch_mc_accept(hipStream_t s, double* r, const double* r_prop, const double* pred, int is_complex, int n, unsigned step,

@@ -7,7 +7,11 @@ reference (paths relative to /root/reference/gaussian_process_liouville_equation
     acceptance_optimize_displacement   mc.cpp:287-331                -> acceptance_optimize_displacement()
     autocorrelation_optimize_steps     mc.cpp:167-285                -> autocorrelation_optimize_steps()
     element_monte_carlo, monte_carlo_selection   mc.cpp:333-403      -> element_monte_carlo(), monte_carlo_selection()
+    new_point_predict, is_very_small   evolve.cpp:425-478            -> new_point_predict(), is_very_small()
+    generate_extra_points       mc.cpp:59-117                        -> generate_element_extra_points(), generate_extra_points()
+    new_element_point_selection mc.cpp:405-537                       -> new_element_point_selection()
     one tick of main()          main.cpp:143-176                     -> tick(): evolve density and extra points, refit
+    the loop body of main()     main.cpp:136-186                     -> main_tick(): tick + element changes + the three re-optimisation rules
 The reference passes a per-point DistributionFunction (stdafx.h:155) into these loops; here `all_kernels` (a TrainingKernels)
 plays that role and every tick costs three batched predicts instead of 8 one-point predicts per sample (NumPES = 2: what the
 reference instantiates, evolve.cpp:367-371).
@@ -169,6 +173,99 @@ def monte_carlo_selection(density, MCParams, all_kernels, seed, api=None):
     return out
 
 
+def new_point_predict(r, iPES, jPES, mass, dt, all_kernels, model=DAC, api=None):
+    """evolve.cpp:425-443 at all points r (n, 2) at once: what element (iPES, jPES) would be there after one more tick according to
+    the current fits of all elements (three-branch back-propagation, no exact density); 0 where the point does not couple."""
+    r = np.asarray(r, dtype=float).reshape(-1, 2)
+    dens = _points({})
+    dens[(iPES, jPES)] = (r, np.zeros(len(r), dtype=complex))
+    return _api(all_kernels, api).evolve(_fits(all_kernels), model, float(np.ravel(mass)[0]), dt, dens, new_points=True)[(iPES, jPES)][1]
+
+
+def is_very_small(density, mass, dt, all_kernels, model=DAC, api=None):
+    """evolve.cpp:445-478: {(iPES, jPES): bool}.  An element that has points is not small; one without is small when the new-point
+    prediction stays below 1e-5 in modulus at every point of element (0, 0)."""
+    pts = _points(density)
+    test = pts[(0, 0)][0]
+    out = {}
+    for e in _ORDER:
+        out[e] = len(pts[e][0]) == 0 and bool(np.all(np.abs(new_point_predict(test, e[0], e[1], mass, dt, all_kernels, model, api)) ** 2 < 1e-10))
+    return out
+
+
+def generate_element_extra_points(points, NumExtraPoints, distribution, rng):
+    """mc.cpp:59-98: NumExtraPoints points, each a selected point (cyclically) plus a normal deviate with the per-coordinate standard
+    deviation of the selected points, with the distribution evaluated there.  rng: numpy Generator (the reference: its shared engine)."""
+    r = np.asarray(points[0], dtype=float)
+    std = np.sqrt(np.maximum((r ** 2).mean(axis=0) - r.mean(axis=0) ** 2, 0.0))  # calculate_standard_deviation_one_surface
+    new = r[np.arange(NumExtraPoints) % len(r)] + rng.normal(size=(NumExtraPoints, 2)) * std
+    return new, np.asarray(distribution(new), dtype=complex)
+
+
+def generate_extra_points(density, NumExtraPoints, all_kernels, rng, api=None):
+    """mc.cpp:100-117 with the fits as the distribution (main.cpp:67,160,169,185)"""
+    a, fits, out = _api(all_kernels, api), _fits(all_kernels), {}
+    for k, e in enumerate(_ORDER):
+        pts = _points(density)[e]
+        if len(pts[0]) == 0:
+            out[e] = pts
+            continue
+        out[e] = generate_element_extra_points(pts, NumExtraPoints, lambda r, k=k: a.predict_batch(fits, r, np.full(len(r), k, dtype=np.int32)), rng)
+    return out
+
+
+def host_chain(distribution, rng):
+    """Metropolis chains (mc.cpp:118-165) against an arbitrary batched distribution — for an element that has no fit yet, whose weight
+    is the new-point prediction; one distribution call (= one device batch) per step.  Same call shape as the device chains."""
+
+    def run(NumSteps, d, r, seed=None, want_chain=False):
+        r = np.asarray(r, dtype=float).copy()
+        w_old = np.abs(distribution(r))
+        acc, whole = np.zeros(len(r)), [r.copy()]
+        for _ in range(int(NumSteps)):
+            r_new = r + rng.uniform(-d, d, size=r.shape)
+            w_new = np.abs(distribution(r_new))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ok = (w_new > w_old) | (w_new / w_old > rng.uniform(size=len(r)))
+            r, w_old = np.where(ok[:, None], r_new, r), np.where(ok, w_new, w_old)
+            acc += ok
+            if want_chain:
+                whole.append(r.copy())
+        res = (r, acc / max(1, int(NumSteps)))
+        return res + (np.stack(whole),) if want_chain else res
+
+    return run
+
+
+def new_element_point_selection(density, extra_points, IsSmallOld, IsSmall, MCParams, all_kernels, mass, dt, rng, model=DAC, api=None):
+    """mc.cpp:405-537: an element that stopped being small gets the NumPoints candidates of largest |new-point prediction| among all
+    current points of all elements (replicated up to NumPoints if fewer are non-zero), a Metropolis re-selection against that
+    prediction, and fresh extra points; an element that became small loses its points.  Returns (density, extra_points)."""
+    if IsSmallOld == IsSmall:
+        return density, extra_points
+    dens, extra = dict(_points(density)), dict(_points(extra_points))
+    NumPoints, NumExtraPoints = len(dens[(0, 0)][0]), len(extra[(0, 0)][0])
+    candidates = np.concatenate([np.asarray(x[e][0], dtype=float).reshape(-1, 2) for e in _ORDER for x in (dens, extra)])
+    seeds = _Seeds(int(rng.integers(1, 2 ** 62)))
+    for e in _ORDER:
+        if IsSmallOld[e] and not IsSmall[e]:
+            distribution = lambda r, e=e: new_point_predict(r, e[0], e[1], mass, dt, all_kernels, model, api)
+            rho = distribution(candidates)
+            keep = min(NumPoints, int(np.count_nonzero(rho)))
+            order = np.argsort(-np.abs(rho) ** 2, kind="stable")[:keep]  # the `keep` most important points (nth_element + erase)
+            r_sel, rho_sel = candidates[order], rho[order]
+            while NumPoints >= 2 * len(r_sel) > 0:
+                r_sel, rho_sel = np.concatenate([r_sel, r_sel]), np.concatenate([rho_sel, rho_sel])
+            if 0 < len(r_sel) < NumPoints:
+                fill = NumPoints - len(r_sel)
+                r_sel, rho_sel = np.concatenate([r_sel, r_sel[:fill]]), np.concatenate([rho_sel, rho_sel[:fill]])
+            dens[e] = element_monte_carlo((r_sel, rho_sel), MCParams[e], host_chain(distribution, rng), distribution, seeds)
+            extra[e] = generate_element_extra_points(dens[e], NumExtraPoints, distribution, rng)
+        elif not IsSmallOld[e] and IsSmall[e]:
+            dens[e] = extra[e] = (np.zeros((0, 2)), np.zeros(0, dtype=complex))
+    return dens, extra
+
+
 def tick(density, extra_points, ParameterVectors, mass, dt, all_kernels, model=DAC, api=None):
     """main.cpp:143-176 without the re-optimisation branches: evolve the density and the extra points against the current
     kernels, then refit the kernels on the evolved density (TrainingKernels(params, density), predict.cpp:390-393)."""
@@ -178,3 +275,43 @@ def tick(density, extra_points, ParameterVectors, mass, dt, all_kernels, model=D
     sets = K.construct_training_sets({e: v for e, v in density.items() if len(v[0])}, 2)
     new_kernels = K.TrainingKernels(ParameterVectors, sets, True, True, False, api=api, num_pes=2)
     return density, extra_points, new_kernels
+
+
+def main_tick(iTick, density, extra_points, IsSmall, MCParams, optimizer, all_kernels, mass, dt, ReoptFreq, NumExtraPoints, Purity, rng,
+              model=DAC, api=None):
+    """main.cpp:136-186, one pass of the evolution loop with everything the reference does in it: evolve the density and the extra
+    points against the current kernels; detect elements that became populated / negligible (is_very_small) and re-select their
+    points (new_element_point_selection); re-optimise the hyper-parameters when an element changed, every ReoptFreq ticks, or when
+    the refitted kernels miss the population or the purity by more than twice AverageTolerance; refit the kernels.
+    optimizer: optimization.Optimization.  Returns (density, extra_points, IsSmall, all_kernels, opt_result | None)."""
+    from . import optimization as O
+    api = _api(all_kernels, api)
+    IsSmallOld = dict(IsSmall)
+    density = evolve(density, mass, dt, all_kernels, model, api)
+    extra_points = evolve(extra_points, mass, dt, all_kernels, model, api)
+    IsSmall = is_very_small(density, mass, dt, all_kernels, model, api)
+    opt_result = None
+
+    def refit(params):
+        sets = K.construct_training_sets({e: v for e, v in density.items() if len(v[0])}, 2)
+        return K.TrainingKernels(params, sets, True, True, False, api=api, num_pes=2)
+
+    def reoptimise():
+        nonlocal all_kernels, extra_points
+        res = optimizer.optimize({e: v for e, v in density.items() if len(v[0])}, {e: v for e, v in extra_points.items() if len(v[0])})
+        all_kernels = refit(optimizer.get_parameters())
+        extra_points = generate_extra_points(density, NumExtraPoints, all_kernels, rng, api)
+        return res
+
+    if IsSmallOld != IsSmall:  # main.cpp:148-163
+        density, extra_points = new_element_point_selection(density, extra_points, IsSmallOld, IsSmall, MCParams, all_kernels, mass, dt, rng, model, api)
+        opt_result = reoptimise()
+    elif iTick % ReoptFreq == 0:  # :165-172
+        opt_result = reoptimise()
+    else:  # :174-189
+        all_kernels = refit(optimizer.get_parameters())
+        pop, pur = all_kernels.calculate_population(), all_kernels.calculate_purity()
+        tol = 2.0 * O.AverageTolerance
+        if pur > (1.0 + tol) * Purity or pop > 1.0 + tol or pop < 1.0 - tol:
+            opt_result = reoptimise()
+    return density, extra_points, IsSmall, all_kernels, opt_result

@@ -302,6 +302,11 @@ typedef struct gple_points
 	double* rho;
 	size_t n;
 } gple_points;
+/* flags: GPLE_IO_DEVICE, and GPLE_EVOLVE_NEW_POINTS = new_point_predict (evolve.cpp:425-443) for every point instead of a tick:
+ * the points stay where they are, rho (input ignored) receives the density the three-branch back-propagation predicts there
+ * from the fits alone — no exact density enters — or 0 where the point does not couple (what is_very_small, evolve.cpp:445-478,
+ * and new_element_point_selection, mc.cpp:405-537, evaluate for an element that has no points yet). */
+#define GPLE_EVOLVE_NEW_POINTS 0x400u
 int gple_evolve(gple_ctx* ctx, const gple_element elements[3], int pes_model, double mass, double dt, gple_points density[3],
 	unsigned flags);
 

@@ -203,6 +203,29 @@ def evolve(density, mass, dt, distribution, model):
 _M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
 
 
+def new_point_predict(r, mass, dt, distribution, row, col, model):
+    """evolve.cpp:425-443 for every row of r: the back-propagated prediction without an exact density where the point couples, else 0"""
+    r = np.asarray(r, dtype=float).reshape(-1, 2)
+    out = np.zeros(len(r), dtype=complex)
+    cpl = is_coupling(r[:, 0], r[:, 1], mass, dt, model)
+    if cpl.any():
+        out[cpl] = non_adiabatic_evolve_predict(r[cpl], None, mass, dt, distribution, row, col, model)
+    return out
+
+
+def is_very_small(density, mass, dt, distribution, model):
+    """evolve.cpp:445-478: an element without points is small when the new-point prediction is below 1e-5 in modulus at every point of
+    element (0, 0); an element with points is not small"""
+    out = {}
+    test = np.asarray(density[(0, 0)][0], dtype=float)
+    for e in [(0, 0), (1, 0), (1, 1)]:
+        if len(density[e][0]) == 0:
+            out[e] = bool(np.all(np.abs(new_point_predict(test, mass, dt, distribution, e[0], e[1], model)) ** 2 < 1e-10))
+        else:
+            out[e] = False
+    return out
+
+
 def philox4x32(counter, key):
     """counter: (..., 4) uint32, key: (2,) -> (..., 4) uint32 (10 rounds)"""
     c = np.array(counter, dtype=np.uint64) & 0xFFFFFFFF

@@ -183,3 +183,86 @@ def test_monte_carlo_selection_on_the_device(gpu, oracle):
         assert (np.abs(rg - ro).max(axis=1) <= 1e-10).mean() >= 0.9
     fg = kg(0)._fit
     assert np.abs(rhog.real - gpu.real_predict(fg, rg, want=("cutoff",))["cutoff"]).max() <= 1e-12 * np.abs(rhog).max() and np.all(rhog.imag == 0)
+
+
+def test_new_point_predict_and_is_very_small(gpu, oracle):
+    """gple_evolve with GPLE_EVOLVE_NEW_POINTS (evolve.cpp:425-443: back-propagated prediction at points that are not moved, no exact
+    density, 0 where uncoupled) and is_very_small (:445-478) against the oracle, for every target element"""
+    from gaussian_process_liouville_equation_amd import steploop as S
+    dens = _case(100, 41)
+    kg = K.TrainingKernels({(0, 0): TH, (1, 0): THC, (1, 1): TH}, K.construct_training_sets(dens), True, True, False, api=gpu)
+    fo = _fits(oracle, dens)
+    dist = _oracle_distribution(oracle, fo)
+    rng = np.random.default_rng(5)
+    pts = dens[(0, 0)][0][:60] + rng.normal(0, 0.1, (60, 2))
+    pts[:5, 0] = 25.0  # far outside the coupling region of the model: uncoupled points -> exactly 0
+    for e in [(0, 0), (1, 0), (1, 1)]:
+        got = S.new_point_predict(pts, e[0], e[1], MASS, DT, kg, S.DAC)
+        ref = E.new_point_predict(pts, MASS, DT, dist, e[0], e[1], E.DAC)
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(got - ref).max() <= 1e-9 * scale, (e, np.abs(got - ref).max(), scale)
+        cpl = E.is_coupling(pts[:, 0], pts[:, 1], MASS, DT, E.DAC)
+        assert np.all(got[~cpl] == 0)
+    # an element without points: small or not as the oracle says; elements with points are never small
+    only00 = {(0, 0): dens[(0, 0)], (1, 0): (np.zeros((0, 2)), np.zeros(0, dtype=complex)), (1, 1): (np.zeros((0, 2)), np.zeros(0, dtype=complex))}
+    k00 = K.TrainingKernels({(0, 0): TH, (1, 0): THC, (1, 1): TH}, K.construct_training_sets(only00), True, True, False, api=gpu)
+    fo00 = [oracle.real_fit(TH, *only00[(0, 0)], 0), None, None]
+    small_g = S.is_very_small(only00, MASS, DT, k00, S.DAC)
+    small_o = E.is_very_small(only00, MASS, DT, _oracle_distribution(oracle, fo00), E.DAC)
+    assert small_g == small_o and small_g[(0, 0)] is False
+
+
+def test_new_element_point_selection_on_the_device(gpu):
+    """mc.cpp:405-537 on the device predictors: the newly populated element gets NumPoints points whose densities are the new-point
+    prediction there, and NumExtraPoints extra points; an element that became small is emptied; nothing changes without a change"""
+    from gaussian_process_liouville_equation_amd import steploop as S
+    dens = _case(64, 43)
+    extra = _case(96, 44)
+    empty = (np.zeros((0, 2)), np.zeros(0, dtype=complex))
+    d0 = {(0, 0): dens[(0, 0)], (1, 0): dens[(1, 0)], (1, 1): empty}
+    x0 = {(0, 0): extra[(0, 0)], (1, 0): extra[(1, 0)], (1, 1): empty}
+    params = {(0, 0): TH, (1, 0): THC, (1, 1): TH}
+    kg = K.TrainingKernels(params, K.construct_training_sets(d0), True, True, False, api=gpu)
+    mc = {e: S.MCParameters() for e in d0}
+    old = {(0, 0): False, (1, 0): False, (1, 1): True}
+    same_d, same_x = S.new_element_point_selection(d0, x0, old, dict(old), mc, kg, MASS, DT, np.random.default_rng(1))
+    assert same_d is d0 and same_x is x0
+    new = {(0, 0): False, (1, 0): True, (1, 1): False}  # (1,1) appears, (1,0) disappears
+    orig = (S.acceptance_optimize_displacement.__defaults__, S.autocorrelation_optimize_steps.__defaults__)
+    S.acceptance_optimize_displacement.__defaults__, S.autocorrelation_optimize_steps.__defaults__ = (12,), (24,)  # short tuning runs
+    try:
+        d1, x1 = S.new_element_point_selection(d0, x0, old, new, mc, kg, MASS, DT, np.random.default_rng(2))
+    finally:
+        S.acceptance_optimize_displacement.__defaults__, S.autocorrelation_optimize_steps.__defaults__ = orig
+    assert len(d1[(1, 0)][0]) == 0 and len(x1[(1, 0)][0]) == 0
+    r11, rho11 = d1[(1, 1)]
+    assert r11.shape == (64, 2) and x1[(1, 1)][0].shape == (96, 2)
+    ref = S.new_point_predict(r11, 1, 1, MASS, DT, kg, S.DAC)
+    assert np.abs(rho11 - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-30)
+    assert np.array_equal(d1[(0, 0)][0], d0[(0, 0)][0])
+
+
+def test_main_tick_rules(gpu):
+    """steploop.main_tick (main.cpp:136-186): without an element change and off the re-optimisation beat the kernels are only refitted
+    on the evolved points; on the beat (iTick % ReoptFreq == 0) the optimiser runs and fresh extra points are drawn"""
+    from gaussian_process_liouville_equation_amd import optimization as O, steploop as S
+    rng = np.random.default_rng(3)
+    sig, x0, p0 = np.array([0.7086, 0.7056]), -10.0, 14.112  # far from the crossing: nothing couples, no element appears
+    wig = lambda r: np.exp(-0.5 * (((r - [x0, p0]) / sig) ** 2).sum(axis=1)) / (2 * np.pi * sig.prod())
+    r, re = rng.normal(size=(80, 2)) * sig + [x0, p0], rng.normal(size=(160, 2)) * sig + [x0, p0]
+    empty = (np.zeros((0, 2)), np.zeros(0, dtype=complex))
+    dens = {(0, 0): (r, wig(r).astype(complex)), (1, 0): empty, (1, 1): empty}
+    extra = {(0, 0): (re, wig(re).astype(complex)), (1, 0): empty, (1, 1): empty}
+    e0 = O.calculate_total_energy_average_one_surface(dens[(0, 0)], MASS, 0)
+    opt = O.Optimization(sig, (x0 - 5, p0 - 5), (x0 + 5, p0 + 5), MASS, e0, 1.0, api=gpu, num_pes=2, local_maxeval=60, searches="native")
+    opt.optimize({(0, 0): dens[(0, 0)]}, {(0, 0): extra[(0, 0)]})
+    k0 = K.TrainingKernels(opt.get_parameters(), K.construct_training_sets({(0, 0): dens[(0, 0)]}, 2), True, True, False, api=gpu, num_pes=2)
+    small = {(0, 0): False, (1, 0): True, (1, 1): True}
+    mc = {e: S.MCParameters() for e in dens}
+    d1, x1, s1, k1, res1 = S.main_tick(1, dens, extra, small, mc, opt, k0, MASS, DT, 2, 160, 1.0, rng, S.DAC, gpu)
+    assert res1 is None and s1 == small and len(d1[(1, 0)][0]) == 0
+    assert np.abs(d1[(0, 0)][0][:, 0] - (r[:, 0] + DT * r[:, 1] / MASS)).max() < 1e-2  # free flight on a flat stretch of the surface
+    assert abs(k1.calculate_population() - 1.0) < 0.1
+    d2, x2, s2, k2, res2 = S.main_tick(2, d1, x1, s1, mc, opt, k1, MASS, DT, 2, 160, 1.0, rng, S.DAC, gpu)
+    assert res2 is not None and len(x2[(0, 0)][0]) == 160 and not np.array_equal(x2[(0, 0)][0], x1[(0, 0)][0])
+    assert abs(k2.calculate_population() - 1.0) < 0.1

@@ -108,3 +108,24 @@ def test_monte_carlo_tuning_on_an_analytic_density():
     r1, rho1 = S.element_monte_carlo((r0, rho(r0).astype(complex)), S.MCParameters(), lambda n, dd, r, s, w=False: chain(min(n, 300), dd, r, s, w),
                                      lambda r: rho(r), S._Seeds(5))
     assert r1.shape == r0.shape and np.allclose(rho1, rho(r1)) and np.abs(r1 - r0).max() > 0
+
+
+def test_extra_points_and_host_chain():
+    """steploop.generate_element_extra_points (mc.cpp:59-98) and the host-driven Metropolis chain for elements without a fit"""
+    from gaussian_process_liouville_equation_amd import steploop as S
+    rng = np.random.default_rng(4)
+    sig = np.array([0.7086, 0.7056])
+    rho = lambda r: np.exp(-0.5 * (((np.asarray(r) - [-10.0, 14.112]) / sig) ** 2).sum(axis=1)) / (2 * np.pi * sig.prod())
+    r0 = np.array([-10.0, 14.112]) + sig * rng.normal(size=(50, 2))
+    new, val = S.generate_element_extra_points((r0, rho(r0)), 130, rho, np.random.default_rng(9))
+    assert new.shape == (130, 2) and np.allclose(val, rho(new))
+    std = r0.std(axis=0)
+    dev = new - r0[np.arange(130) % 50]
+    assert np.all(np.abs(dev.std(axis=0) / std - 1.0) < 0.35)
+    chain = S.host_chain(rho, np.random.default_rng(10))
+    last, acc, whole = chain(200, 0.5, r0, None, True)
+    assert whole.shape == (201, 50, 2) and np.array_equal(whole[0], r0) and np.array_equal(whole[-1], last)
+    assert 0.2 < acc.mean() < 0.95 and np.all(np.abs(np.diff(whole, axis=0)).max(axis=(1, 2)) <= 0.5)
+    # the chain samples |rho|: after many steps the walkers' spread is that of the density
+    last, _ = chain(1500, 0.8, np.tile([[-10.0, 14.112]], (400, 1)))
+    assert np.all(np.abs(last.std(axis=0) / sig - 1.0) < 0.2)
