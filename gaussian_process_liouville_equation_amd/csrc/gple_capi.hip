@@ -2205,6 +2205,43 @@ extern "C"
 		return GPLE_OK;
 	}
 
+	/* gple_debug.h: instrumented launches of the one-launch panel step (potrf_step_kernel) at block column 1 of an n x n matrix,
+	 * n = 128 + below (below = 0 | 64), column-major on the host, overwritten with what the first launch leaves; T (n x n) likewise. */
+	int gple_debug_potrf_step(gple_ctx* ctx, double* A, double* T, int pend, int below, long long* stamps, int reps, float* ms_per_launch)
+	{
+		if (!ctx || !A || !T || !stamps || (below != 0 && below != 64)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		const int n = 128 + below;
+		Scratch a(ctx), t(ctx), aux(ctx);
+		GPLE_HIP(ctx, a.get(n * n));
+		GPLE_HIP(ctx, t.get(n * n));
+		GPLE_HIP(ctx, aux.get(40));
+		GPLE_HIP(ctx, hipMemsetAsync(aux.p, 0, 40 * 8, st));
+		GPLE_HIP(ctx, hipMemsetAsync(t.p, 0, sizeof(double) * n * n, st));
+		GPLE_HIP(ctx, copy_in(st, a.p, A, n * n, false));
+		hipEvent_t e0, e1;
+		GPLE_HIP(ctx, hipEventCreate(&e0));
+		GPLE_HIP(ctx, hipEventCreate(&e1));
+		GPLE_HIP(ctx, debug_potrf_step(st, a.p, n, t.p, n, reinterpret_cast<int*>(aux.p), reinterpret_cast<long long*>(aux.p + 8), pend, below));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		GPLE_HIP(ctx, hipMemcpy(A, a.p, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+		GPLE_HIP(ctx, hipMemcpy(T, t.p, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+		GPLE_HIP(ctx, hipEventRecord(e0, st));
+		for (int i = 0; i < reps; ++i)
+			GPLE_HIP(ctx, debug_potrf_step(st, a.p, n, t.p, n, reinterpret_cast<int*>(aux.p), reinterpret_cast<long long*>(aux.p + 8), pend, below));
+		GPLE_HIP(ctx, hipEventRecord(e1, st));
+		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		float ms = 0.f;
+		GPLE_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+		if (ms_per_launch) *ms_per_launch = reps > 0 ? ms / reps : 0.f;
+		(void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+		GPLE_HIP(ctx, hipMemcpy(stamps, aux.p + 8, 24 * 8, hipMemcpyDeviceToHost)); // of the last (warm) launch
+		return GPLE_OK;
+	}
+
 	/* gple_debug.h (not part of include/gple.h): one product of the fp64 MFMA GEMM family on host operands, for tests/test_gpu_gemm.py.
 	 * C(m,n) = alpha sum_k A(m,k) B(n,k) + beta C(m,n); layouts and k-ranges as GemmDesc (csrc/gple_internal.h);
 	 * tile = 32 | 64 | 128 | 0 (the library's own choice for this shape). */

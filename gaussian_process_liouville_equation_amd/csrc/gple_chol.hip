@@ -9,6 +9,8 @@
 // LDLT::info() is never checked, NaN/Inf are clamped later by opt.cpp:420-431).
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -66,6 +68,62 @@ namespace gple
 				else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, y[q], acc, 0, 0, 0);
 			}
 			return K > 4 ? acc + a1 : acc;
+		}
+		// Operands kept k-major (entry (row, k) at [k * DLS + row] — the way a column-major block arrives from global memory, so that
+		// staging it is a copy with the lanes along LDS rows: no transposing stores, which cost an 8-way bank conflict each at this stride).
+		// acc -= X Y^T over K = 64, X rows at xs, Y rows at ys
+		__device__ __forceinline__ d4v tile_mac_kk_neg64(d4v acc, const double* xs, const double* ys, int lane)
+		{
+			const int fr = lane & 15, fk = lane >> 4;
+			double x[16], y[16];
+#pragma unroll
+			for (int q = 0; q < 16; ++q) x[q] = -xs[(4 * q + fk) * DLS + fr], y[q] = ys[(4 * q + fk) * DLS + fr];
+			d4v a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int q = 0; q < 16; q += 2)
+			{
+				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], y[q], acc, 0, 0, 0);
+				a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q + 1], y[q + 1], a1, 0, 0, 0);
+			}
+			return acc + a1;
+		}
+		// two products with a common Y: acc0 -= X0 Y^T, acc1 -= X1 Y^T; one round of operand reads, four MFMA chains
+		__device__ __forceinline__ void tile_mac2_kk_neg64(d4v& acc0, d4v& acc1, const double* xs0, const double* xs1, const double* ys, int lane)
+		{
+			const int fr = lane & 15, fk = lane >> 4;
+			double x0[16], x1[16], y[16];
+#pragma unroll
+			for (int q = 0; q < 16; ++q)
+			{
+				x0[q] = -xs0[(4 * q + fk) * DLS + fr];
+				x1[q] = -xs1[(4 * q + fk) * DLS + fr];
+				y[q] = ys[(4 * q + fk) * DLS + fr];
+			}
+			d4v b0 = {0.0, 0.0, 0.0, 0.0}, b1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int q = 0; q < 16; q += 2)
+			{
+				acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[q], y[q], acc0, 0, 0, 0);
+				acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[q], y[q], acc1, 0, 0, 0);
+				b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[q + 1], y[q + 1], b0, 0, 0, 0);
+				b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[q + 1], y[q + 1], b1, 0, 0, 0);
+			}
+			acc0 += b0, acc1 += b1;
+		}
+		// a tile held transposed (accumulator element q of lane (fk, fr) = entry (row fr, column fk + 4 q)) goes to its place in a row-major LDS block
+		__device__ __forceinline__ d4v tile_load_t(const double* src, int lane)
+		{
+			const int fr = lane & 15, fk = lane >> 4;
+			d4v a;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) a[r] = src[fr * DLS + fk + 4 * r];
+			return a;
+		}
+		__device__ __forceinline__ void tile_store_t(double* dst, d4v a, int lane)
+		{
+			const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) dst[fr * DLS + fk + 4 * r] = a[r];
 		}
 		__device__ __forceinline__ d4v tile_load(const double* src, int lane)
 		{
@@ -358,6 +416,329 @@ namespace gple
 			stamp();
 		}
 
+		// ---- the whole panel step in one launch ----------------------------------------------------------------------------------
+		// potrf_diag_kernel followed by the rank-64 update of the block column's strip is two dependent launches per panel: the
+		// update (5 us, latency-bound) sits on the critical path only because the NEXT panel's own 64 columns are among what it
+		// updates.  Here the panel applies the previous panel's update to its own columns itself (left-looking by exactly one
+		// step: diagonal block before the chain starts, its 64 rows below on four extra waves while wave 0 runs the first two
+		// chains), and the rest of that update — every column right of this panel — is done by further workgroups of the SAME
+		// launch, next to the panel workgroups instead of in front of them.  One launch per panel; no workgroup waits for another:
+		//   workgroups [0, ndt):      panel j0 (as potrf_diag_kernel), `pend`: first subtract L_prev(rows) L_prev(diag rows)^T
+		//   workgroups [ndt, ndt + .): 64 x 64 tiles (r >= c) of  A(c0 + 64 r .., c0 + 64 c ..) -= L_prev(rows r) L_prev(rows c)^T,
+		//                              c0 = j0 + 64, L_prev = A(., j0 - 64 .. j0 - 1); straight from L2 into MFMA fragments, no LDS
+		// 8 waves: waves 4-7 hold the panel rows as MFMA accumulators from the start (no register copy of them on the chain wave)
+		// and share the final product L21 = P T_jj^T with waves 0-3.
+		// Schedule of the pending update of the panel rows (16 tile products of K = 64, tile k = 4 * row tile + column tile).  On gfx950 the
+		// fp64 MFMA runs on the SIMD's fp64 vector ALUs (matrix and vector fp64 peaks are equal): an MFMA on the chain wave's SIMD stalls
+		// the chain (measured: chain stage 3.8k -> 5.8k cycles), and a SIMD gets through about two such products (2 x 1024 MFMA cycles +
+		// LDS round trips) per chain stage of 3.7k.  So wave 4 (SIMD 0, like the chain wave) never multiplies, the first chain stage takes
+		// the six pending diagonal tiles on waves 1-3, waves 6 / 7 (SIMDs 2 / 3) do two row products in each of the other three chain
+		// stages, and the stage of the last 16 x 16 inverse takes the remaining four (wave 5 two: SIMD 1 carries the other inverses
+		// until then).  RU_TILE[wave - 5][slot] = tile, RU_STAGE = 1..3: chain stage, 4: the stage after.
+		constexpr int RU_TILE[3][8] = {{0, 1, -1, -1, -1, -1, -1, -1}, {2, 3, 4, 5, 6, 7, 8, -1}, {9, 10, 12, 13, 14, 15, 11, -1}};
+		constexpr int RU_STAGE[3][8] = {{4, 4, -1, -1, -1, -1, -1, -1}, {1, 1, 2, 2, 3, 3, 4, -1}, {1, 1, 2, 2, 3, 3, 4, -1}};
+		constexpr int ru_find(int wv, int st, int nth) // slot of the nth product wave 5 + wv does in stage st, or -1
+		{
+			int c = 0;
+			for (int sl = 0; sl < 8; ++sl)
+				if (RU_TILE[wv][sl] >= 0 && RU_STAGE[wv][sl] == st)
+				{
+					if (c == nth) return sl;
+					++c;
+				}
+			return -1;
+		}
+		template <int WV, typename F>
+		__device__ __forceinline__ void ru_slots(F&& f)
+		{
+			[&]<int... Sl>(std::integer_sequence<int, Sl...>) { ((RU_TILE[WV][Sl] >= 0 ? f(std::integral_constant<int, Sl>{}) : (void)0), ...); }
+			(std::make_integer_sequence<int, 8>{});
+		}
+
+		template <bool PROBE>
+		__global__ void __launch_bounds__(512) potrf_step_kernel(double* __restrict__ A, long lda, double* __restrict__ T, long ldt, int* __restrict__ info,
+			int j0, int below, int ndt, int pend, int sy_nc, int sy_nr, double* __restrict__ uvec, long long* __restrict__ stamps)
+		{
+			int stamp_i = 0;
+			auto stamp = [&]() {
+				if constexpr (PROBE)
+					if (threadIdx.x == 0 && blockIdx.x == 0) stamps[stamp_i++] = static_cast<long long>(__builtin_readcyclecounter());
+			};
+			stamp();
+			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+			const int fr = lane & 15, fk = lane >> 4;
+			if (static_cast<int>(blockIdx.x) >= ndt)
+			{
+				// tile id -> (column block c, row block r >= c) of the strip
+				int id = static_cast<int>(blockIdx.x) - ndt, c = 0;
+				while (id >= sy_nr - c) id -= sy_nr - c, ++c;
+				const int r = c + id;
+				const long c0 = j0 + NB;
+				const double* __restrict__ Lr = A + (c0 + static_cast<long>(r) * NB) + static_cast<long>(j0 - NB) * lda; // rows of the result tile
+				const double* __restrict__ Lc = A + (c0 + static_cast<long>(c) * NB) + static_cast<long>(j0 - NB) * lda; // its columns, as rows of L_prev
+				double* __restrict__ C = A + (c0 + static_cast<long>(r) * NB) + (c0 + static_cast<long>(c) * NB) * lda;
+				// accumulator element [i = fk + 4 q][j = fr] = C(row 16 a + j, column 16 b + i): the lanes of a quarter run along a column of C
+				const int a = w & 3, b0 = 2 * (w >> 2);
+				d4v acc[2];
+				double y[16], x[2][16];
+#pragma unroll
+				for (int u = 0; u < 2; ++u)
+#pragma unroll
+					for (int q = 0; q < 4; ++q) acc[u][q] = C[(16 * a + fr) + static_cast<long>(16 * (b0 + u) + fk + 4 * q) * lda];
+#pragma unroll
+				for (int q = 0; q < 16; ++q)
+				{
+					y[q] = Lr[(16 * a + fr) + static_cast<long>(4 * q + fk) * lda];
+#pragma unroll
+					for (int u = 0; u < 2; ++u) x[u][q] = -Lc[(16 * (b0 + u) + fr) + static_cast<long>(4 * q + fk) * lda];
+				}
+#pragma unroll
+				for (int q = 0; q < 16; ++q)
+#pragma unroll
+					for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][q], y[q], acc[u], 0, 0, 0);
+#pragma unroll
+				for (int u = 0; u < 2; ++u)
+#pragma unroll
+					for (int q = 0; q < 4; ++q) C[(16 * a + fr) + static_cast<long>(16 * (b0 + u) + fk + 4 * q) * lda] = acc[u][q];
+				return;
+			}
+			__shared__ __attribute__((aligned(16))) double S[NB * DLS];  // A_jj -> L_jj (strictly lower tiles); later the panel rows
+			__shared__ __attribute__((aligned(16))) double TI[NB * DLS]; // T_jj; tile (i, b), b < i, holds V(i, b) until T(i, b) replaces it
+			__shared__ __attribute__((aligned(16))) double U[NB * DLS];  // pend: this workgroup's 64 rows of L_prev, k-major; at the end the result tiles on their way out
+			__shared__ __attribute__((aligned(16))) double D[NB * DLS];  // pend: the diagonal rows of L_prev, k-major
+			__shared__ double rinv[NB];
+			const double* __restrict__ Ajj = A + j0 + static_cast<long>(j0) * lda;
+			const bool has_rows = static_cast<int>(blockIdx.x) * NB < below; // uniform
+			double* const Pb = A + (j0 + NB + static_cast<long>(blockIdx.x) * NB) + static_cast<long>(j0) * lda;
+			{
+				const int r = t & 63;
+#pragma unroll
+				for (int q = 0; q < 8; ++q)
+				{
+					const int c = (t >> 6) + 8 * q;
+					S[r * DLS + c] = Ajj[r + static_cast<long>(c) * lda];
+				}
+				if (pend)
+				{
+					const double* __restrict__ Ld = Ajj - static_cast<long>(NB) * lda;
+#pragma unroll
+					for (int q = 0; q < 8; ++q)
+					{
+						const int c = (t >> 6) + 8 * q;
+						D[c * DLS + r] = Ld[r + static_cast<long>(c) * lda];
+					}
+				}
+			}
+			d4v pacc[8];
+			int first_bad = 0;
+			auto Sx = [&](int ti, int tj) { return S + ti * 16 * DLS + tj * 16; };
+			auto Tx = [&](int ti, int tj) { return TI + ti * 16 * DLS + tj * 16; };
+			auto upd = [&](int ti, int tj, int sp) {
+				d4v acc = tile_load(Sx(ti, tj), lane);
+				acc = tile_mac<true, true, 16>(acc, Sx(ti, sp), Sx(tj, sp), lane);
+				tile_store(Sx(ti, tj), acc, lane);
+			};
+			// the previous panel's update of diagonal tile (ti, tj)
+			auto pend_upd = [&](int ti, int tj) {
+				d4v acc = tile_load(Sx(ti, tj), lane);
+				acc = tile_mac_kk_neg64(acc, D + ti * 16, D + tj * 16, lane);
+				tile_store(Sx(ti, tj), acc, lane);
+			};
+			// tiles (a, c) and (b, c) of the diagonal block at once; first_t: the first one is (c, a) held transposed instead
+			auto pend_upd2 = [&](int a, int c0, int b, int c, bool first_t) {
+				d4v acc0 = first_t ? tile_load_t(Sx(a, c0), lane) : tile_load(Sx(a, c0), lane);
+				d4v acc1 = tile_load(Sx(b, c), lane);
+				tile_mac2_kk_neg64(acc0, acc1, D + (first_t ? c0 : a) * 16, D + b * 16, D + (first_t ? a : c) * 16, lane);
+				if (first_t) tile_store_t(Sx(a, c0), acc0, lane);
+				else tile_store(Sx(a, c0), acc0, lane);
+				tile_store(Sx(b, c), acc1, lane);
+			};
+			// the panel rows: pick-up, the pending update stage by stage, hand-over to S (waves 5-7, RU_TILE / RU_STAGE)
+			// (waves 5-7 hold their tiles TRANSPOSED — lanes run along the rows of the panel, so that the loads below are 128-byte segments;
+			// an 8-byte gather costs the address unit ~60 cycles per instruction — and the products are formed as D_j U_i^T accordingly)
+			auto rows_pick = [&]<int WV>(std::integral_constant<int, WV>) {
+				ru_slots<WV>([&](auto sl) {
+					constexpr int k = RU_TILE[WV][decltype(sl)::value];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) pacc[decltype(sl)::value][q] = Pb[(16 * (k >> 2) + fr) + static_cast<long>(16 * (k & 3) + fk + 4 * q) * lda];
+				});
+			};
+			auto rows_mac = [&]<int WV, int ST>(std::integral_constant<int, WV>, std::integral_constant<int, ST>) {
+				constexpr int s0 = ru_find(WV, ST, 0), s1 = ru_find(WV, ST, 1);
+				if constexpr (s0 >= 0 && s1 >= 0)
+				{
+					constexpr int k0 = RU_TILE[WV][s0], k1 = RU_TILE[WV][s1];
+					static_assert((k0 >> 2) == (k1 >> 2), "the two products of a stage share their row tile");
+					tile_mac2_kk_neg64(pacc[s0], pacc[s1], D + (k0 & 3) * 16, D + (k1 & 3) * 16, U + (k0 >> 2) * 16, lane);
+				}
+				else if constexpr (s0 >= 0)
+				{
+					constexpr int k0 = RU_TILE[WV][s0];
+					pacc[s0] = tile_mac_kk_neg64(pacc[s0], D + (k0 & 3) * 16, U + (k0 >> 2) * 16, lane);
+				}
+			};
+			auto rows_put = [&]<int WV>(std::integral_constant<int, WV>) {
+				ru_slots<WV>([&](auto sl) {
+					constexpr int k = RU_TILE[WV][decltype(sl)::value];
+					tile_store_t(Sx(k >> 2, k & 3), pacc[decltype(sl)::value], lane);
+				});
+			};
+			auto rows_stage = [&]<int ST>(std::integral_constant<int, ST> st) {
+				if (w == 5) rows_mac(std::integral_constant<int, 0>{}, st);
+				else if (w == 6) rows_mac(std::integral_constant<int, 1>{}, st);
+				else if (w == 7) rows_mac(std::integral_constant<int, 2>{}, st);
+			};
+			auto v_acc = [&](int i, int b, int k, bool first) {
+				d4v acc = {0.0, 0.0, 0.0, 0.0};
+				if (!first) acc = tile_load(Tx(i, b), lane);
+				acc = tile_mac<false, false, 16>(acc, Sx(i, k), Tx(k, b), lane);
+				tile_store(Tx(i, b), acc, lane);
+			};
+			auto t_fin = [&](int i, int b) {
+				d4v acc = {0.0, 0.0, 0.0, 0.0};
+				acc = tile_mac<false, true, 16>(acc, Tx(i, i), Tx(i, b), lane);
+				tile_store(Tx(i, b), acc, lane);
+			};
+			__syncthreads();
+			stamp();
+			// what is not needed before the second chain is requested here and arrives during the first: the panel rows (waves 5-7, straight
+			// into their accumulators) and, pending, this workgroup's rows of L_prev (waves 4-7 -> U, published by the barrier after the chain)
+			const int tt = t & 255;
+			double uv[16];
+			if (has_rows && pend && w >= 4)
+			{
+				const double* __restrict__ Lb = Pb - static_cast<long>(NB) * lda;
+#pragma unroll
+				for (int q = 0; q < 16; ++q) uv[q] = Lb[(tt & 63) + static_cast<long>((tt >> 6) + 4 * q) * lda];
+			}
+			if (pend)
+			{
+				// what the first chain reads: tile column 0; the other six lower tiles follow during the first chain (SIMDs 1-3).
+				// The barrier orders LDS only (s_waitcnt lgkmcnt(0)): __syncthreads() would also wait for the loads just issued.
+				if (w < 4) pend_upd(w, 0);
+				asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+				stamp();
+			}
+			if (has_rows)
+			{
+				if (w == 5) rows_pick(std::integral_constant<int, 0>{});
+				else if (w == 6) rows_pick(std::integral_constant<int, 1>{});
+				else if (w == 7) rows_pick(std::integral_constant<int, 2>{});
+				if (pend && w >= 4)
+#pragma unroll
+					for (int q = 0; q < 16; ++q) U[((tt >> 6) + 4 * q) * DLS + (tt & 63)] = uv[q];
+			}
+			if (w == 0) diag_chain<0>(S, rinv, lane, first_bad);
+			else if (pend)
+			{
+				// two tiles per wave with a common second factor; (3, 1) is formed transposed (D_1 D_3^T) to share D_3 with (3, 3)
+				if (w == 1) pend_upd2(1, 1, 2, 1, false);
+				else if (w == 2) pend_upd2(2, 2, 3, 2, false);
+				else if (w == 3) pend_upd2(3, 1, 3, 3, true);
+			}
+			__syncthreads();
+			stamp();
+			if (w == 0) upd(1, 1, 0);
+			else if (w == 1) upd(2, 1, 0);
+			else if (w == 2) upd(3, 1, 0);
+			else if (w == 3) upd(2, 2, 0);
+			__syncthreads();
+			stamp();
+			if (w == 0) diag_chain<1>(S, rinv, lane, first_bad);
+			else if (w == 1) diag_inv16(S, rinv, TI, 0, lane);
+			else if (w == 2) upd(3, 2, 0);
+			else if (w == 3) upd(3, 3, 0);
+			else if (pend && has_rows) rows_stage(std::integral_constant<int, 1>{});
+			__syncthreads();
+			stamp();
+			if (w == 0) upd(2, 2, 1);
+			else if (w == 1) upd(3, 2, 1);
+			else if (w == 2) upd(3, 3, 1);
+			else if (w == 3) v_acc(1, 0, 0, true);
+			__syncthreads();
+			stamp();
+			if (w == 0) diag_chain<2>(S, rinv, lane, first_bad);
+			else if (w == 1) diag_inv16(S, rinv, TI, 1, lane);
+			else if (w == 2) v_acc(2, 0, 0, true);
+			else if (w == 3) v_acc(3, 0, 0, true);
+			else if (pend && has_rows) rows_stage(std::integral_constant<int, 2>{});
+			__syncthreads();
+			stamp();
+			if (w == 0) upd(3, 3, 2);
+			else if (w == 1) t_fin(1, 0);
+			else if (w == 2) v_acc(2, 1, 1, true);
+			else if (w == 3) v_acc(3, 1, 1, true);
+			__syncthreads();
+			stamp();
+			if (w == 0) diag_chain<3>(S, rinv, lane, first_bad);
+			else if (w == 1) diag_inv16(S, rinv, TI, 2, lane);
+			else if (w == 2) v_acc(2, 0, 1, false);
+			else if (w == 3) v_acc(3, 0, 1, false);
+			else if (pend && has_rows) rows_stage(std::integral_constant<int, 3>{});
+			__syncthreads();
+			stamp();
+			if (w == 0) diag_inv16(S, rinv, TI, 3, lane);
+			else if (w == 1) t_fin(2, 0), v_acc(3, 0, 2, false); // LDS operations of one wave complete in order
+			else if (w == 2) t_fin(2, 1), v_acc(3, 1, 2, false);
+			else if (w == 3) v_acc(3, 2, 2, true);
+			if (w >= 5 && pend && has_rows) rows_stage(std::integral_constant<int, 4>{});
+			__syncthreads();
+			stamp();
+			if (w < 3) t_fin(3, w);
+			if (has_rows) // L_jj is dead since the last barrier: the panel rows take its place
+			{
+				if (w == 5) rows_put(std::integral_constant<int, 0>{});
+				else if (w == 6) rows_put(std::integral_constant<int, 1>{});
+				else if (w == 7) rows_put(std::integral_constant<int, 2>{});
+			}
+			__syncthreads();
+			stamp();
+			if (blockIdx.x == 0)
+			{
+				const int r = t & 63;
+				double* __restrict__ Tjj = T + j0 + static_cast<long>(j0) * ldt;
+#pragma unroll
+				for (int q = 0; q < 8; ++q)
+				{
+					const int c = (t >> 6) + 8 * q;
+					Tjj[r + static_cast<long>(c) * ldt] = c <= r ? TI[r * DLS + c] : 0.0;
+				}
+				if (first_bad != 0 && t == 0) atomicCAS(info, 0, j0 + first_bad); // info starts at 0; first_bad is wave 0's
+			}
+			if (has_rows)
+			{
+				// L21(row tile, 16 j ..) = sum_{k <= 16 j + 15} P(., k) T_jj(16 j .., k): waves w and w + 4 share row tile w & 3 — column tiles
+				// {0, 3} and {1, 2}, 20 MFMAs each; the results meet in U (dead by now), transposed for coalesced stores
+				const int rt = w & 3;
+				if (w < 4)
+				{
+					const d4v o0 = tile_mac<true, false, 16>((d4v){0.0, 0.0, 0.0, 0.0}, S + rt * 16 * DLS, TI, lane);
+					const d4v o3 = tile_mac<true, false, 64>((d4v){0.0, 0.0, 0.0, 0.0}, S + rt * 16 * DLS, TI + 48 * DLS, lane);
+					tile_store(U + rt * 16 * DLS, o0, lane);
+					tile_store(U + rt * 16 * DLS + 48, o3, lane);
+				}
+				else
+				{
+					const d4v o1 = tile_mac<true, false, 32>((d4v){0.0, 0.0, 0.0, 0.0}, S + rt * 16 * DLS, TI + 16 * DLS, lane);
+					const d4v o2 = tile_mac<true, false, 48>((d4v){0.0, 0.0, 0.0, 0.0}, S + rt * 16 * DLS, TI + 32 * DLS, lane);
+					tile_store(U + rt * 16 * DLS + 16, o1, lane);
+					tile_store(U + rt * 16 * DLS + 32, o2, lane);
+				}
+				__syncthreads();
+			stamp();
+				const int r = t & 63;
+#pragma unroll
+				for (int q = 0; q < 8; ++q)
+				{
+					const int c = (t >> 6) + 8 * q;
+					Pb[r + static_cast<long>(c) * lda] = U[r * DLS + c];
+				}
+				// the label row carried below the matrix (chol_inverse_factor, `uvec`): its factor entries are u = L^-1 y, 64 per panel
+				if (uvec != nullptr && static_cast<int>(blockIdx.x) == ndt - 1 && t < NB) uvec[j0 + t] = U[t];
+			}
+			stamp();
+		}
+
 		// upper(i<j) = lower(j,i) for a full symmetric result
 		__global__ void __launch_bounds__(256) mirror_lower_kernel(double* __restrict__ W, long ldw, int n)
 		{
@@ -378,19 +759,54 @@ namespace gple
 	} // namespace
 
 	// Two-level blocking.  A 64-wide panel step that updates the WHOLE trailing matrix reads and writes it once per panel:
-	// 8 n^3 / (3 * 64) bytes in total, 2.9 GB at n = 4096 — the K = 64 updates run at HBM speed, not MFMA speed (1.07 ms of
-	// the 3.3 ms fit).  With an outer block of OB columns the panel steps only update the rest of their own block column
-	// (a strip of <= OB - 64 columns), and the matrix right of the block gets ONE update with K = OB per outer block: a
-	// quarter of the traffic at OB = 256, at four times the arithmetic intensity.  Small matrices keep the plain scheme
-	// (their updates are latency-bound launches either way).
-	static int chol_outer_block(int n)
+	// 8 n^3 / (3 * 64) bytes in total, 2.9 GB at n = 4096 — the K = 64 updates run at HBM speed, not MFMA speed.  With outer blocks
+	// the panel steps only update the rest of their own block (a strip), and the matrix right of the block gets ONE update with
+	// K = the block's width per outer block.  In the one-launch panel step the strip's tiles run beside the panel workgroups for
+	// free as long as they are done before the panel is (~14 us: about GPLE_CHOL_TILE_BUDGET = 800 tiles of 2-3 us on the CUs the
+	// panel leaves idle), so every outer block is made as wide as that budget allows at its first panel — the blocks widen as the
+	// trailing matrix shrinks (n = 4096: 832 + 1088 + 2176; below n ~ 2400 the whole matrix is one block), which also makes the
+	// K of the separate updates large.  GPLE_CHOL_OUTER = <width> forces equal blocks (0: a single one) for A/B runs.
+	static const std::vector<int>& chol_block_bounds(int n)
 	{
 		static const int forced = [] {
 			const char* e = getenv("GPLE_CHOL_OUTER");
 			return e ? atoi(e) : -1;
 		}();
-		if (forced >= 0) return forced >= NB ? forced / NB * NB : 0;
-		return n >= 2048 ? 256 : 0;
+		static const int budget = [] {
+			const char* e = getenv("GPLE_CHOL_TILE_BUDGET");
+			return e && atoi(e) > 0 ? atoi(e) : 800;
+		}();
+		static const bool fused = [] {
+			const char* e = getenv("GPLE_CHOL_FUSED");
+			return e == nullptr || atoi(e) != 0;
+		}();
+		static std::mutex mu;
+		static std::map<int, std::vector<int>> cache;
+		std::lock_guard<std::mutex> lk(mu);
+		auto it = cache.find(n);
+		if (it != cache.end()) return it->second;
+		std::vector<int> b{0};
+		if (forced >= 0 || !fused)
+		{
+			const int OB = forced >= NB ? forced / NB * NB : (forced < 0 && n >= 2048 ? 256 : 0);
+			if (OB)
+				for (int j = OB; j < n; j += OB) b.push_back(j);
+		}
+		else
+			for (int J0 = 0; J0 < n;)
+			{
+				// widest block whose first strip (nc column blocks right of the panel, nr row blocks below it) stays within the budget
+				const int nr = (n - J0) / NB - 1;
+				int nc = 0;
+				while (nc < nr && (nc + 1) * nr - (nc + 1) * nc / 2 <= budget) ++nc;
+				int w = (nc + 1) * NB;
+				if (w < 256) w = 256;
+				if (n - (J0 + w) < 256) w = n - J0; // no sliver at the end
+				J0 += w;
+				if (J0 < n) b.push_back(J0);
+			}
+		b.push_back(n);
+		return cache.emplace(n, std::move(b)).first->second;
 	}
 
 	// panel steps of the block columns [j_begin, j_end) (multiples of NB; j_begin on an outer-block boundary or 0) of the n x n matrix
@@ -398,7 +814,7 @@ namespace gple
 	// along as part of every panel, which leaves u = L^-1 y in its first row — collected into uvec — at no extra launch
 	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end, double* uvec)
 	{
-		const int OB = chol_outer_block(n);
+		const std::vector<int>& bounds = chol_block_bounds(n);
 		auto at = [&](int r, int c) { return A + r + static_cast<long>(c) * lda; };
 		// C(r0.., c0..) -= A(r0.., k0..k0+K) A(c0.., k0..k0+K)^T on the lower tiles of an m x ncols result whose (0,0) lies on the diagonal
 		auto syrk_update = [&](int r0, int m, int ncols, int k0, int K) -> hipError_t {
@@ -410,25 +826,48 @@ namespace gple
 			// n = 4096, 12.25 vs 11.16 at 8192; K = 256 is too short for that kernel's two-slab pipeline)
 			return launch_gemm(s, g, gemm_pick_tile(m, ncols, 1, true));
 		};
+		static const bool fused = [] {
+			const char* e = getenv("GPLE_CHOL_FUSED");
+			return e == nullptr || atoi(e) != 0;
+		}();
+		bool pend = false; // the rank-64 update by the previous panel has not been applied yet (fused scheme: it rides in the next launch)
 		for (int j0 = j_begin; j0 < j_end; j0 += NB)
 		{
-			const int J0 = OB ? j0 / OB * OB : 0;                      // outer block column of this panel
-			const int Jend = OB ? (J0 + OB < n ? J0 + OB : n) : n;
+			size_t bi = 0;
+			while (bounds[bi + 1] <= j0) ++bi;
+			const int J0 = bounds[bi], Jend = bounds[bi + 1]; // outer block of this panel
 			const int extra = uvec ? NB : 0;
 			const int m = n + extra - j0; // rows of the panel including the diagonal block
 			const int below = m - NB;
+			const int ndt = below > 0 ? below / NB : 1;
+			const int strip = Jend - (j0 + NB); // columns of this block column right of the panel
+			if (fused)
+			{
+				// one launch: the panel (with the previous panel's update of its own columns, if pending) + the rest of that update
+				const int sy_nc = pend ? strip / NB : 0, sy_nr = pend ? below / NB : 0;
+				const int ntiles = sy_nc * sy_nr - sy_nc * (sy_nc - 1) / 2;
+				hipLaunchKernelGGL(potrf_step_kernel<false>, dim3(ndt + ntiles), dim3(512), 0, s, A, lda, T, ldt, info, j0, below, ndt, pend ? 1 : 0, sy_nc, sy_nr, uvec,
+					static_cast<long long*>(nullptr));
+				pend = strip > 0;
+				if (pend && j0 + NB >= j_end) // nobody comes after this panel in this call: apply its update now
+				{
+					const hipError_t e = syrk_update(j0 + NB, below, strip, j0, NB);
+					if (e != hipSuccess) return e;
+					pend = false;
+				}
+			}
+			else
 			{
 				// diagonal block + the rows below it: one launch, one workgroup per 64 panel rows (each re-does the diagonal block)
 				double* Tjj = T + j0 + static_cast<long>(j0) * ldt;
-				const int ndt = below > 0 ? below / NB : 1;
 				hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(ndt), dim3(256), 0, s, at(j0, j0), lda, Tjj, ldt, info, j0, static_cast<long long*>(nullptr),
 					at(j0 + (below > 0 ? NB : 0), j0), below, uvec);
-			}
-			// the rest of this block column: rows j0 + NB .. n, columns j0 + NB .. Jend
-			if (Jend - (j0 + NB) > 0)
-			{
-				const hipError_t e = syrk_update(j0 + NB, below, Jend - (j0 + NB), j0, NB);
-				if (e != hipSuccess) return e;
+				// the rest of this block column: rows j0 + NB .. n, columns j0 + NB .. Jend
+				if (strip > 0)
+				{
+					const hipError_t e = syrk_update(j0 + NB, below, strip, j0, NB);
+					if (e != hipSuccess) return e;
+				}
 			}
 			// last panel of an outer block: everything right of the block column, once, with K = the block's width
 			if (j0 + NB == Jend && n - Jend > 0)
@@ -444,6 +883,14 @@ namespace gple
 	hipError_t debug_potrf_diag(hipStream_t s, const double* A, double* T, int* info, long long* stamps)
 	{
 		hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), 0, s, A, 64L, T, 64L, info, 0, stamps, const_cast<double*>(A), 0, static_cast<double*>(nullptr));
+		return hipGetLastError();
+	}
+
+	// probe entry: one instrumented launch of the one-launch panel step at j0 = 64 of an n x n matrix (n = 128 + below)
+	hipError_t debug_potrf_step(hipStream_t s, double* A, long lda, double* T, long ldt, int* info, long long* stamps, int pend, int below)
+	{
+		const int ndt = below > 0 ? below / NB : 1;
+		hipLaunchKernelGGL(potrf_step_kernel<true>, dim3(ndt), dim3(512), 0, s, A, lda, T, ldt, info, NB, below, ndt, pend, 0, 0, static_cast<double*>(nullptr), stamps);
 		return hipGetLastError();
 	}
 
@@ -518,10 +965,14 @@ namespace gple
 	// split on an outer-block boundary near the middle: the columns left of H are final once their panels are done
 	static int chol_split_point(int n)
 	{
-		const int nblocks = n / NB, OB = chol_outer_block(n);
-		int H = nblocks / 2 * NB;
-		if (OB) H = (H + OB / 2) / OB * OB;
-		if (H <= 0 || H >= n) H = nblocks / 2 * NB;
+		const std::vector<int>& bounds = chol_block_bounds(n);
+		int H = n / NB / 2 * NB; // a single block may be split anywhere: the panel before the split applies its update itself
+		if (bounds.size() > 2)
+		{
+			H = bounds[1];
+			for (size_t i = 1; i + 1 < bounds.size(); ++i)
+				if (std::abs(bounds[i] - n / 2) < std::abs(H - n / 2)) H = bounds[i];
+		}
 		return H;
 	}
 	size_t chol_inverse_work_doubles(int n)

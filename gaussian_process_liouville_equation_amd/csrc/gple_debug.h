@@ -1,6 +1,7 @@
 /* gple_debug.h — diagnostic entry points of libgple_hip.so that are NOT part of the drop-in C-ABI (include/gple.h): they run one
  * internal kernel family on host operands so that tests and probes can check it in isolation.
  *   tests/test_gpu_chol_diag.py, probes/diag_probe.py -> gple_debug_potrf_diag
+ *   tests/test_gpu_chol_diag.py, probes/step_probe.py -> gple_debug_potrf_step
  *   tests/test_gpu_gemm.py                            -> gple_debug_gemm */
 #ifndef GPLE_DEBUG_H
 #define GPLE_DEBUG_H
@@ -13,6 +14,9 @@ extern "C"
 	 * A: 64 x 64 column-major SPD block; T out: inv(chol(A)); stamps: 16 shader-clock stamps of the kernel's stages;
 	 * ms_per_launch: average over `reps` back-to-back launches. */
 	int gple_debug_potrf_diag(gple_ctx* ctx, const double* A, double* T, long long* stamps, int reps, float* ms_per_launch);
+	/* The one-launch panel step (potrf_step_kernel) at block column 1 of an n x n matrix, n = 128 + below (below = 0 | 64); A and T
+	 * (n x n, column-major) come back as the first launch leaves them; stamps: 24 shader-clock stamps of workgroup 0. */
+	int gple_debug_potrf_step(gple_ctx* ctx, double* A, double* T, int pend, int below, long long* stamps, int reps, float* ms_per_launch);
 	/* C(m,n) = alpha sum_k A(m,k) B(n,k) + beta C(m,n) by the fp64 MFMA GEMM family (gple_gemm.hip); layouts and k-ranges as GemmDesc
 	 * in gple_internal.h; tile = 32 | 64 | 128 | 0 (the library's own choice). */
 	int gple_debug_gemm(gple_ctx* ctx, const double* A, long lda, int a_kmajor, const double* B, long ldb, int b_kmajor, double* C, long ldc,

@@ -48,3 +48,57 @@ def test_diag_block_of_a_gram_matrix(gpu):
     T = _run(gpu, A)
     res = np.abs(T @ A @ T.T - np.eye(64)).max()
     assert res <= 1e-9, res
+
+
+@pytest.mark.parametrize("pend", [0, 1])
+@pytest.mark.parametrize("below", [0, 64])
+@pytest.mark.parametrize("ridge", [0.5, 1e-5])
+def test_one_launch_panel_step(gpu, pend, below, ridge):
+    """potrf_step_kernel (gple_debug_potrf_step): block column 1 of a (128 + below)-square SPD matrix whose block column 0 is already
+    factored.  pend = 1: the update by block column 0 has not been applied and the kernel does it itself (diagonal block before the
+    chain, the rows below on the side waves); either way T_11 = inv(L_11) and the rows below come out as numpy's factor has them."""
+    lib = gpu.lib
+    if not hasattr(lib, "gple_debug_potrf_step"):
+        pytest.fail("libgple_hip.so lacks gple_debug_potrf_step")
+    lib.gple_debug_potrf_step.restype = ctypes.c_int
+    n = 128 + below
+    rng = np.random.default_rng(10 * pend + below)
+    B = rng.standard_normal((n, 2 * n))
+    K = B @ B.T / (2 * n) + ridge * np.eye(n)
+    L = np.linalg.cholesky(K)
+    A = K.copy()
+    A[:, :64] = L[:, :64]
+    if not pend:
+        A[64:, 64:] -= L[64:, :64] @ L[64:, :64].T
+    A = np.asfortranarray(A)
+    T = np.zeros((n, n), order="F")
+    stamps = np.zeros(24, dtype=np.int64)
+    ms = ctypes.c_float()
+    rc = lib.gple_debug_potrf_step(gpu.ctx, A.ctypes.data_as(ctypes.c_void_p), T.ctypes.data_as(ctypes.c_void_p), pend, below,
+                                   stamps.ctypes.data_as(ctypes.c_void_p), 0, ctypes.byref(ms))
+    assert rc == 0
+    Tjj, Ljj = T[64:128, 64:128], L[64:128, 64:128]
+    assert np.all(np.triu(Tjj, 1) == 0.0)
+    scale = np.linalg.cond(Ljj)
+    assert np.abs(Tjj @ Ljj - np.eye(64)).max() <= 64 * 2.3e-16 * scale * 8
+    if below:
+        assert np.abs(A[128:, 64:128] - L[128:, 64:128]).max() <= 64 * 2.3e-16 * scale * 8 * np.abs(L).max()
+    # nothing outside block column 1 is touched by the panel workgroups
+    assert np.array_equal(A[:, :64], L[:, :64])
+
+
+@pytest.mark.parametrize("N", [192, 448, 1088, 2496, 4352])
+def test_factorisation_identities_across_outer_block_layouts(gpu, N):
+    """the whole factorisation at sizes whose outer-block layouts differ (chol_block_bounds: one block up to ~2400 columns, then several
+    of growing width; N = 1088 and up also take the two-stream split): K W = I and K v = y to rounding, LOOCV error from the getters"""
+    from gaussian_process_liouville_equation_amd import _capi as c
+    from tests import parity
+    X, y, _ = parity.synthetic_real(N, 8, 777 + N)
+    fit = gpu.real_fit([1.0, 0.7086, 0.7056, 1e-2], X, y, 3)
+    assert fit.scalars["info"] == 0
+    K, W, v, ys = fit.get(c.R_KERNEL), fit.get(c.R_INVERSE), fit.get(c.R_INVLBL), fit.get(c.R_LABEL)
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    assert n1(K @ W - np.eye(N)) <= 50 * N * parity.EPS * n1(K) * n1(W)
+    assert np.abs(K @ v - ys).max() <= 50 * N * parity.EPS * (n1(K) * np.abs(v).max() + np.abs(ys).max())
+    assert abs(((v / np.diag(W)) ** 2).sum() - fit.scalars["error"]) <= 1e-9 * fit.scalars["error"]
+    fit.release()
