@@ -149,7 +149,7 @@ static void ctx_drop(gple_ctx* ctx)
 	{
 		(void)hipStreamSynchronize(ctx->side_stream);
 		(void)hipStreamDestroy(ctx->side_stream);
-		if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+		for (hipEvent_t ev : ctx->side_forks) (void)hipEventDestroy(ev);
 		if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
 	}
 	if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);

@@ -9,6 +9,7 @@
 // LDLT::info() is never checked, NaN/Inf are clamped later by opt.cpp:420-431).
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -812,7 +813,9 @@ namespace gple
 	// panel steps of the block columns [j_begin, j_end) (multiples of NB; j_begin on an outer-block boundary or 0) of the n x n matrix
 	// uvec != nullptr: A carries one more block row (rows n .. n + NB - 1, row n = the scaled labels y, the rest zero); it is factored
 	// along as part of every panel, which leaves u = L^-1 y in its first row — collected into uvec — at no extra launch
-	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end, double* uvec)
+	// on_final(j): called right after the launch that makes the columns [0, j) of the factor (and their T_jj) final, for every j in `marks`
+	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end, double* uvec,
+		const std::vector<int>* marks = nullptr, const std::function<hipError_t(int)>* on_final = nullptr)
 	{
 		const std::vector<int>& bounds = chol_block_bounds(n);
 		auto at = [&](int r, int c) { return A + r + static_cast<long>(c) * lda; };
@@ -848,6 +851,11 @@ namespace gple
 				const int ntiles = sy_nc * sy_nr - sy_nc * (sy_nc - 1) / 2;
 				hipLaunchKernelGGL(potrf_step_kernel<false>, dim3(ndt + ntiles), dim3(512), 0, s, A, lda, T, ldt, info, j0, below, ndt, pend ? 1 : 0, sy_nc, sy_nr, uvec,
 					static_cast<long long*>(nullptr));
+				if (marks && std::find(marks->begin(), marks->end(), j0 + NB) != marks->end())
+				{
+					const hipError_t e = (*on_final)(j0 + NB);
+					if (e != hipSuccess) return e;
+				}
 				pend = strip > 0;
 				if (pend && j0 + NB >= j_end) // nobody comes after this panel in this call: apply its update now
 				{
@@ -862,6 +870,11 @@ namespace gple
 				double* Tjj = T + j0 + static_cast<long>(j0) * ldt;
 				hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(ndt), dim3(256), 0, s, at(j0, j0), lda, Tjj, ldt, info, j0, static_cast<long long*>(nullptr),
 					at(j0 + (below > 0 ? NB : 0), j0), below, uvec);
+				if (marks && std::find(marks->begin(), marks->end(), j0 + NB) != marks->end())
+				{
+					const hipError_t e = (*on_final)(j0 + NB);
+					if (e != hipSuccess) return e;
+				}
 				// the rest of this block column: rows j0 + NB .. n, columns j0 + NB .. Jend
 				if (strip > 0)
 				{
@@ -953,7 +966,7 @@ namespace gple
 		return hipGetLastError();
 	}
 
-	// Smallest n for which the leading half's inverse goes to the side stream (two event hand-overs cost about 10 us)
+	// Smallest n for which the inverse runs beside the factorisation on the side stream (an event hand-over costs the main stream ~6 us)
 	static int chol_overlap_min_n()
 	{
 		static const int v = [] {
@@ -962,30 +975,56 @@ namespace gple
 		}();
 		return v;
 	}
-	// split on an outer-block boundary near the middle: the columns left of H are final once their panels are done
-	static int chol_split_point(int n)
+	// The inverse by block rows, beside the factorisation.  T = L^-1 row block by row block: once the panels of the column range
+	// [g0, g1) are done, everything its row block of T needs is final — T_gg from the merge tree over its diagonal blocks, then
+	// T(g, 0..g0) = -T_gg (L(g, 0..g0) T(0..g0, 0..g0)), two triangular-k GEMMs — so the side stream of the context works through the row
+	// blocks while the main stream keeps factoring, and only the last row block is left when the last panel is done.  The first form of
+	// this (one split in the middle, both halves' trees + a 2048-wide join after the last panel at n = 4096) left 0.5 ms behind the last
+	// panel; the work of a row block grows with g0^2, so the groups shrink towards the end: fork points at 60 % and 80 % of n
+	// (GPLE_CHOL_FORKS = comma-separated percentages for A/B runs), none closer than 256 columns to its neighbours.
+	static const std::vector<int>& chol_fork_points(int n)
 	{
-		const std::vector<int>& bounds = chol_block_bounds(n);
-		int H = n / NB / 2 * NB; // a single block may be split anywhere: the panel before the split applies its update itself
-		if (bounds.size() > 2)
+		static const std::vector<int> pct = [] {
+			std::vector<int> v;
+			if (const char* e = getenv("GPLE_CHOL_FORKS"))
+			{
+				for (const char* p = e; *p;)
+				{
+					v.push_back(atoi(p));
+					while (*p && *p != ',') ++p;
+					if (*p == ',') ++p;
+				}
+			}
+			else v = {60, 80};
+			return v;
+		}();
+		static std::mutex mu;
+		static std::map<int, std::vector<int>> cache;
+		std::lock_guard<std::mutex> lk(mu);
+		auto it = cache.find(n);
+		if (it != cache.end()) return it->second;
+		std::vector<int> f;
+		int next = n; // from the last one down: the late fork matters most
+		for (auto it2 = pct.rbegin(); it2 != pct.rend(); ++it2)
 		{
-			H = bounds[1];
-			for (size_t i = 1; i + 1 < bounds.size(); ++i)
-				if (std::abs(bounds[i] - n / 2) < std::abs(H - n / 2)) H = bounds[i];
+			const int j = static_cast<int>(static_cast<long>(n) * *it2 / 100) / NB * NB;
+			if (*it2 <= 0 || *it2 >= 100 || next - j < 256 || j < 256) continue;
+			f.insert(f.begin(), j), next = j;
 		}
-		return H;
+		return cache.emplace(n, std::move(f)).first->second;
 	}
 	size_t chol_inverse_work_doubles(int n)
 	{
-		// last merge: W = L21 T11, (n - H) x H; a tree over h columns needs at most h^2 / 4 (one pair spanning everything)
-		const size_t H = static_cast<size_t>(chol_split_point(n)), R = static_cast<size_t>(n) - H;
-		return R * H + H * H / 4 + R * R / 4 + static_cast<size_t>(n) * static_cast<size_t>(n) / 4 + 64; // last term: the unsplit path
+		// W = L(g, 0..g0) T(0..g0) of a row block: <= n^2 / 4; merge trees of the side and of the main stream: <= n^2 / 4 (the unsplit path) and n^2 / 16
+		const size_t q = static_cast<size_t>(n) * static_cast<size_t>(n) / 4;
+		return q + q + q / 4 + 64;
 	}
 	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work, double* uvec)
 	{
 		if (n % NB) return hipErrorInvalidValue;
 		const int nblocks = n / NB;
-		if (n < chol_overlap_min_n() || nblocks < 4)
+		const std::vector<int>& forks = chol_fork_points(n);
+		if (n < chol_overlap_min_n() || nblocks < 4 || forks.empty())
 		{
 			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info, uvec);
 			if (e != hipSuccess) return e;
@@ -995,40 +1034,61 @@ namespace gple
 		if (!ctx->side_stream)
 		{
 			if ((e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)) != hipSuccess) return e;
-			if ((e = hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming)) != hipSuccess) return e;
 			if ((e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming)) != hipSuccess) return e;
 		}
-		hipStream_t side = ctx->side_stream;
-		const int H = chol_split_point(n);
-		const size_t Hs = static_cast<size_t>(H), Rs = static_cast<size_t>(n - H);
-		double* w_top = work;                      // (n - H) x H
-		double* w_lead = w_top + Rs * Hs;          // tree of the leading half
-		double* w_trail = w_lead + Hs * Hs / 4;    // tree of the trailing half
-		// main stream: leading block columns
-		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, H, uvec)) != hipSuccess) return e;
-		if ((e = hipEventRecord(ctx->side_fork, s)) != hipSuccess) return e;
-		// side stream: T11 = L11^-1 and W = L21 T11, all inputs final
-		if ((e = hipStreamWaitEvent(side, ctx->side_fork, 0)) != hipSuccess) return e;
-		if ((e = trtri_lower_from_diag(side, A, lda, T, ldt, H, w_lead)) != hipSuccess) return e;
+		while (ctx->side_forks.size() < forks.size())
 		{
-			GemmDesc g{};
-			g.A = A + H, g.lda = lda, g.B = T, g.ldb = ldt, g.C = w_top, g.ldc = n - H;
-			g.M = n - H, g.N = H, g.K = H, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
-			g.krange = K_GE_N, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
-			if ((e = launch_gemm(side, g, gemm_pick_tile(n - H, H, 1, true))) != hipSuccess) return e;
+			hipEvent_t ev;
+			if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+			ctx->side_forks.push_back(ev);
 		}
+		hipStream_t side = ctx->side_stream;
+		const size_t q = static_cast<size_t>(n) * static_cast<size_t>(n) / 4;
+		double* w_prod = work;          // W of the row block in flight (side jobs are serial; the last one runs after the join)
+		double* w_side = work + q;      // merge tree of a side job
+		double* w_main = work + 2 * q;  // merge tree of the last row block (main stream, beside the side's last job)
+		// row block [g0, g1) of T: its diagonal block by the merge tree, W = L(g, 0..g0) T(0..g0, 0..g0), T(g, 0..g0) = -T_gg W
+		auto tree = [&](hipStream_t st, int g0, int g1, double* w_tree) -> hipError_t {
+			return trtri_lower_from_diag(st, A + g0 + static_cast<long>(g0) * lda, lda, T + g0 + static_cast<long>(g0) * ldt, ldt, g1 - g0, w_tree);
+		};
+		auto w_product = [&](hipStream_t st, int g0, int g1) -> hipError_t {
+			GemmDesc g{};
+			g.A = A + g0, g.lda = lda, g.B = T, g.ldb = ldt, g.C = w_prod, g.ldc = g1 - g0;
+			g.M = g1 - g0, g.N = g0, g.K = g0, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
+			g.krange = K_GE_N, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
+			return launch_gemm(st, g, gemm_pick_tile(g1 - g0, g0, 1, true));
+		};
+		auto t_product = [&](hipStream_t st, int g0, int g1) -> hipError_t {
+			GemmDesc g{};
+			g.A = T + g0 + static_cast<long>(g0) * ldt, g.lda = ldt, g.B = w_prod, g.ldb = g1 - g0, g.C = T + g0, g.ldc = ldt;
+			g.M = g1 - g0, g.N = g0, g.K = g1 - g0, g.batch = 1, g.alpha = -1.0, g.beta = 0.0;
+			g.krange = K_LE_M, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
+			return launch_gemm(st, g, gemm_pick_tile(g1 - g0, g0, 1, true));
+		};
+		int done = 0;
+		size_t nfork = 0;
+		const std::function<hipError_t(int)> on_final = [&](int j) -> hipError_t {
+			hipError_t er;
+			hipEvent_t ev = ctx->side_forks[nfork++];
+			if ((er = hipEventRecord(ev, s)) != hipSuccess) return er;
+			if ((er = hipStreamWaitEvent(side, ev, 0)) != hipSuccess) return er;
+			if ((er = tree(side, done, j, w_side)) != hipSuccess) return er;
+			if (done > 0)
+			{
+				if ((er = w_product(side, done, j)) != hipSuccess) return er;
+				if ((er = t_product(side, done, j)) != hipSuccess) return er;
+			}
+			done = j;
+			// the rows below the last fork are final in these columns too: their W is formed here, beside the remaining panels
+			if (nfork == forks.size()) er = w_product(side, j, n);
+			return er;
+		};
+		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n, uvec, &forks, &on_final)) != hipSuccess) return e;
 		if ((e = hipEventRecord(ctx->side_join, side)) != hipSuccess) return e;
-		// main stream meanwhile: trailing block columns and their inverse
-		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, H, n, uvec)) != hipSuccess) return e;
-		double* T22 = T + H + static_cast<long>(H) * ldt;
-		if ((e = trtri_lower_from_diag(s, A + H + static_cast<long>(H) * lda, lda, T22, ldt, n - H, w_trail)) != hipSuccess) return e;
-		// join: T21 = -T22 W
+		// the last row block: its tree does not need the side's results, the last product does
+		if ((e = tree(s, done, n, w_main)) != hipSuccess) return e;
 		if ((e = hipStreamWaitEvent(s, ctx->side_join, 0)) != hipSuccess) return e;
-		GemmDesc g{};
-		g.A = T22, g.lda = ldt, g.B = w_top, g.ldb = n - H, g.C = T + H, g.ldc = ldt;
-		g.M = n - H, g.N = H, g.K = n - H, g.batch = 1, g.alpha = -1.0, g.beta = 0.0;
-		g.krange = K_LE_M, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
-		return launch_gemm(s, g, gemm_pick_tile(n - H, H, 1, true));
+		return t_product(s, done, n);
 	}
 
 	hipError_t lauum_full(hipStream_t s, const double* T, long ldt, double* W, long ldw, int n)

@@ -76,7 +76,8 @@ namespace gple
 		// second stream + two events for the part of a fit that does not sit on the factorisation's critical path (created on
 		// first use by chol_inverse_factor; the main stream waits for the side work before anything reads its results)
 		hipStream_t side_stream = nullptr;
-		hipEvent_t side_fork = nullptr, side_join = nullptr;
+		hipEvent_t side_join = nullptr;
+		std::vector<hipEvent_t> side_forks;
 		// pinned host block for scalar results
 		double* host_scalars = nullptr;
 		// device counters of the predict path's far-row pruning: [0] blocks contracted, [1] blocks seen (lazily allocated)
