@@ -1033,7 +1033,14 @@ namespace gple
 		hipError_t e;
 		if (!ctx->side_stream)
 		{
-			if ((e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+			// the side stream's GEMMs fill whatever the panel launches leave idle and must not be dispatched ahead of them: lowest priority
+			static const int side_prio = [] {
+				const char* ev = getenv("GPLE_CHOL_SIDE_PRIORITY"); // 0: default priority (A/B)
+				int lo = 0, hi = 0;
+				if ((ev && atoi(ev) == 0) || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return 0;
+				return lo;
+			}();
+			if ((e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, side_prio)) != hipSuccess) return e;
 			if ((e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming)) != hipSuccess) return e;
 		}
 		while (ctx->side_forks.size() < forks.size())
