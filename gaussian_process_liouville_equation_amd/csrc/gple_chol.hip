@@ -425,7 +425,7 @@ namespace gple
 		// chains), and the rest of that update — every column right of this panel — is done by further workgroups of the SAME
 		// launch, next to the panel workgroups instead of in front of them.  One launch per panel; no workgroup waits for another:
 		//   workgroups [0, ndt):      panel j0 (as potrf_diag_kernel), `pend`: first subtract L_prev(rows) L_prev(diag rows)^T
-		//   workgroups [ndt, ndt + .): 64 x 64 tiles (r >= c) of  A(c0 + 64 r .., c0 + 64 c ..) -= L_prev(rows r) L_prev(rows c)^T,
+		//   workgroups [ndt, ndt + .): four 64 x 64 tiles (r >= c) each of  A(c0 + 64 r .., c0 + 64 c ..) -= L_prev(rows r) L_prev(rows c)^T,
 		//                              c0 = j0 + 64, L_prev = A(., j0 - 64 .. j0 - 1); straight from L2 into MFMA fragments, no LDS
 		// 8 waves: waves 4-7 hold the panel rows as MFMA accumulators from the start (no register copy of them on the chain wave)
 		// and share the final product L21 = P T_jj^T with waves 0-3.
@@ -470,8 +470,10 @@ namespace gple
 			const int fr = lane & 15, fk = lane >> 4;
 			if (static_cast<int>(blockIdx.x) >= ndt)
 			{
-				// tile id -> (column block c, row block r >= c) of the strip
-				int id = static_cast<int>(blockIdx.x) - ndt, c = 0;
+				// four 64 x 64 tiles per workgroup, a wave pair each (tile id -> column block c, row block r >= c of the strip); a wave owns
+				// 2 x 4 of its tile's 16 x 16 blocks: 6 operand fragments per 8 MFMAs, K in two halves of 32
+				int id = 4 * (static_cast<int>(blockIdx.x) - ndt) + (w >> 1), c = 0;
+				if (id >= sy_nr * sy_nc - sy_nc * (sy_nc - 1) / 2) return; // wave-uniform; no barrier on this path
 				while (id >= sy_nr - c) id -= sy_nr - c, ++c;
 				const int r = c + id;
 				const long c0 = j0 + NB;
@@ -479,28 +481,40 @@ namespace gple
 				const double* __restrict__ Lc = A + (c0 + static_cast<long>(c) * NB) + static_cast<long>(j0 - NB) * lda; // its columns, as rows of L_prev
 				double* __restrict__ C = A + (c0 + static_cast<long>(r) * NB) + (c0 + static_cast<long>(c) * NB) * lda;
 				// accumulator element [i = fk + 4 q][j = fr] = C(row 16 a + j, column 16 b + i): the lanes of a quarter run along a column of C
-				const int a = w & 3, b0 = 2 * (w >> 2);
-				d4v acc[2];
-				double y[16], x[2][16];
+				const int a0 = 2 * (w & 1);
+				d4v acc[2][4];
 #pragma unroll
 				for (int u = 0; u < 2; ++u)
 #pragma unroll
-					for (int q = 0; q < 4; ++q) acc[u][q] = C[(16 * a + fr) + static_cast<long>(16 * (b0 + u) + fk + 4 * q) * lda];
+					for (int b = 0; b < 4; ++b)
 #pragma unroll
-				for (int q = 0; q < 16; ++q)
+						for (int q = 0; q < 4; ++q) acc[u][b][q] = C[(16 * (a0 + u) + fr) + static_cast<long>(16 * b + fk + 4 * q) * lda];
+#pragma unroll
+				for (int kh = 0; kh < 2; ++kh)
 				{
-					y[q] = Lr[(16 * a + fr) + static_cast<long>(4 * q + fk) * lda];
+					double y[2][8], x[4][8];
 #pragma unroll
-					for (int u = 0; u < 2; ++u) x[u][q] = -Lc[(16 * (b0 + u) + fr) + static_cast<long>(4 * q + fk) * lda];
+					for (int q = 0; q < 8; ++q)
+					{
+						const long kcol = static_cast<long>(32 * kh + 4 * q + fk) * lda;
+#pragma unroll
+						for (int u = 0; u < 2; ++u) y[u][q] = Lr[(16 * (a0 + u) + fr) + kcol];
+#pragma unroll
+						for (int b = 0; b < 4; ++b) x[b][q] = -Lc[(16 * b + fr) + kcol];
+					}
+#pragma unroll
+					for (int q = 0; q < 8; ++q)
+#pragma unroll
+						for (int u = 0; u < 2; ++u)
+#pragma unroll
+							for (int b = 0; b < 4; ++b) acc[u][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[b][q], y[u][q], acc[u][b], 0, 0, 0);
 				}
 #pragma unroll
-				for (int q = 0; q < 16; ++q)
-#pragma unroll
-					for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][q], y[q], acc[u], 0, 0, 0);
-#pragma unroll
 				for (int u = 0; u < 2; ++u)
 #pragma unroll
-					for (int q = 0; q < 4; ++q) C[(16 * a + fr) + static_cast<long>(16 * (b0 + u) + fk + 4 * q) * lda] = acc[u][q];
+					for (int b = 0; b < 4; ++b)
+#pragma unroll
+						for (int q = 0; q < 4; ++q) C[(16 * (a0 + u) + fr) + static_cast<long>(16 * b + fk + 4 * q) * lda] = acc[u][b][q];
 				return;
 			}
 			__shared__ __attribute__((aligned(16))) double S[NB * DLS];  // A_jj -> L_jj (strictly lower tiles); later the panel rows
@@ -849,7 +863,7 @@ namespace gple
 				// one launch: the panel (with the previous panel's update of its own columns, if pending) + the rest of that update
 				const int sy_nc = pend ? strip / NB : 0, sy_nr = pend ? below / NB : 0;
 				const int ntiles = sy_nc * sy_nr - sy_nc * (sy_nc - 1) / 2;
-				hipLaunchKernelGGL(potrf_step_kernel<false>, dim3(ndt + ntiles), dim3(512), 0, s, A, lda, T, ldt, info, j0, below, ndt, pend ? 1 : 0, sy_nc, sy_nr, uvec,
+				hipLaunchKernelGGL(potrf_step_kernel<false>, dim3(ndt + (ntiles + 3) / 4), dim3(512), 0, s, A, lda, T, ldt, info, j0, below, ndt, pend ? 1 : 0, sy_nc, sy_nr, uvec,
 					static_cast<long long*>(nullptr));
 				if (marks && std::find(marks->begin(), marks->end(), j0 + NB) != marks->end())
 				{
