@@ -2239,6 +2239,11 @@ extern "C"
 		if (ms_per_launch) *ms_per_launch = reps > 0 ? ms / reps : 0.f;
 		(void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
 		GPLE_HIP(ctx, hipMemcpy(stamps, aux.p + 8, 24 * 8, hipMemcpyDeviceToHost)); // of the last (warm) launch
+		{
+			int info = 0; // as the first launch left it (atomicCAS from 0): reported in the last stamp slot
+			GPLE_HIP(ctx, hipMemcpy(&info, aux.p, sizeof(int), hipMemcpyDeviceToHost));
+			stamps[23] = info;
+		}
 		return GPLE_OK;
 	}
 

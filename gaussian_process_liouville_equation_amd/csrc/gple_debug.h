@@ -15,7 +15,7 @@ extern "C"
 	 * ms_per_launch: average over `reps` back-to-back launches. */
 	int gple_debug_potrf_diag(gple_ctx* ctx, const double* A, double* T, long long* stamps, int reps, float* ms_per_launch);
 	/* The one-launch panel step (potrf_step_kernel) at block column 1 of an n x n matrix, n = 128 + below (below = 0 | 64); A and T
-	 * (n x n, column-major) come back as the first launch leaves them; stamps: 24 shader-clock stamps of workgroup 0. */
+	 * (n x n, column-major) come back as the first launch leaves them; stamps: 24 slots — shader-clock stamps of workgroup 0, the last slot = `info` (0, or 1 + the first column whose pivot was not positive). */
 	int gple_debug_potrf_step(gple_ctx* ctx, double* A, double* T, int pend, int below, long long* stamps, int reps, float* ms_per_launch);
 	/* C(m,n) = alpha sum_k A(m,k) B(n,k) + beta C(m,n) by the fp64 MFMA GEMM family (gple_gemm.hip); layouts and k-ranges as GemmDesc
 	 * in gple_internal.h; tile = 32 | 64 | 128 | 0 (the library's own choice). */

@@ -102,3 +102,38 @@ def test_factorisation_identities_across_outer_block_layouts(gpu, N):
     assert np.abs(K @ v - ys).max() <= 50 * N * parity.EPS * (n1(K) * np.abs(v).max() + np.abs(ys).max())
     assert abs(((v / np.diag(W)) ** 2).sum() - fit.scalars["error"]) <= 1e-9 * fit.scalars["error"]
     fit.release()
+
+
+@pytest.mark.parametrize("pend", [0, 1])
+def test_panel_step_reports_a_non_positive_pivot(gpu, pend):
+    """reference behaviour (LDLT::info() is never checked, kernel.cpp:281-283): the factorisation does not stop at a non-positive pivot;
+    here NaN runs through the block's results and info names the first offending column (1-based, in matrix coordinates)"""
+    lib = gpu.lib
+    lib.gple_debug_potrf_step.restype = ctypes.c_int
+    n, bad = 192, 37
+    rng = np.random.default_rng(3 + pend)
+    B = rng.standard_normal((n, 2 * n))
+    K = B @ B.T / (2 * n) + 0.5 * np.eye(n)
+    L = np.linalg.cholesky(K)
+    A = K.copy()
+    A[:, :64] = L[:, :64]
+    S = K[64:, 64:] - L[64:, :64] @ L[64:, :64].T  # what block column 1 factors
+    # make the pivot of column `bad` of the diagonal block negative: lower that diagonal entry below what the first `bad` columns take away
+    Ld = np.linalg.cholesky(S[:64, :64])
+    drop = (Ld[bad, bad] ** 2) * 1.5
+    if pend:
+        A[64 + bad, 64 + bad] -= drop
+    else:
+        A[64:, 64:] = S
+        A[64 + bad, 64 + bad] -= drop
+    A = np.asfortranarray(A)
+    T = np.zeros((n, n), order="F")
+    stamps = np.zeros(24, dtype=np.int64)
+    ms = ctypes.c_float()
+    rc = lib.gple_debug_potrf_step(gpu.ctx, A.ctypes.data_as(ctypes.c_void_p), T.ctypes.data_as(ctypes.c_void_p), pend, 64,
+                                   stamps.ctypes.data_as(ctypes.c_void_p), 0, ctypes.byref(ms))
+    assert rc == 0
+    assert stamps[23] == 64 + bad + 1
+    assert np.isnan(T[64:128, 64:128]).any() and np.isnan(A[128:, 64:128]).any()
+    lo = bad // 16 * 16  # NaN spreads through the 16 x 16 tile products of its own sub-panel; the rows above it never see it
+    assert np.all(np.isfinite(T[64:64 + lo, 64:64 + lo]))
