@@ -341,7 +341,15 @@ namespace
 			Xin = xtmp.p, yin = ytmp.p;
 		}
 		GPLE_HIP(ctx, launch_prep_labels(st, yin, y_stride, f->is_complex ? 1 : 0, f->N, Np, f->ys, f->sdev, Xin, f->Xt, SDEV_N));
-		GPLE_HIP(ctx, hipMemsetAsync(f->T, 0, static_cast<size_t>(nt) * nt * 8, st));
+		// T is lower block-triangular and every consumer keeps to the blocks on and below the diagonal (the diagonal 64-blocks leave the
+		// panel step complete, zeros above the diagonal included), so the blocks above are never written and never read: no 8 n^2-byte
+		// memset in front of the factorisation (35 us at n = 4096).  GPLE_POISON_T=1 fills T with NaN bit patterns first — the GPU
+		// test session runs that way (tests/conftest.py), so a reader of an unwritten block cannot go unnoticed.
+		static const bool poison_t = [] {
+			const char* e = getenv("GPLE_POISON_T");
+			return e != nullptr && atoi(e) != 0;
+		}();
+		if (poison_t) GPLE_HIP(ctx, hipMemsetAsync(f->T, 0xFF, static_cast<size_t>(nt) * nt * 8, st));
 		// the scaled labels ride below the matrix as one more block row: its factor is u = L^-1 ys (= T ys, without the two launches)
 		const long ldl = nt + CHOL_NB;
 		GPLE_HIP(ctx, launch_gram_train(st, f->Xt, f->N, Np, nt, f->ps, Lbuf.p, ldl, f->ys));

@@ -388,6 +388,7 @@ namespace gple
 				{
 					const int c = (t >> 6) + 4 * q;
 					T[r + static_cast<long>(c) * ldt] = c <= r ? TI[r * DLS + c] : 0.0;
+					if (j0 & NB) T[r - NB + static_cast<long>(c) * ldt] = 0.0; // see potrf_step_kernel
 				}
 				if (first_bad != 0 && t == 0) atomicCAS(info, 0, j0 + first_bad); // info starts at 0
 			}
@@ -717,6 +718,10 @@ namespace gple
 				{
 					const int c = (t >> 6) + 8 * q;
 					Tjj[r + static_cast<long>(c) * ldt] = c <= r ? TI[r * DLS + c] : 0.0;
+					// the one block above the diagonal that a reader may touch: 128-tile GEMMs with a triangular k-range start at their
+					// 128-aligned diagonal tile, which takes in the block above the second 64-block of the pair.  Nothing else above the
+					// diagonal blocks of T is ever written or read.
+					if (j0 & NB) Tjj[r - NB + static_cast<long>(c) * ldt] = 0.0;
 				}
 				if (first_bad != 0 && t == 0) atomicCAS(info, 0, j0 + first_bad); // info starts at 0; first_bad is wave 0's
 			}

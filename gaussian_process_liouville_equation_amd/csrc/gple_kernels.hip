@@ -164,12 +164,13 @@ namespace gple
 			const bool cross = wx != nullptr && k + shift < n;
 			const double* __restrict__ c2 = T + static_cast<long>(cross ? k + shift : k) * ldt;
 			double av = 0.0, aw = 0.0, ax = 0.0;
+			const int i2 = (k + shift) & ~63; // column k + shift starts at its own diagonal block: the blocks above are never written
 			for (int i = (k & ~63) + lane; i < n; i += 64)
 			{
 				const double tv = c[i];
 				av = fma(tv, u[i], av);
 				aw = fma(tv, tv, aw);
-				if (cross) ax = fma(tv, c2[i], ax);
+				if (cross && i >= i2) ax = fma(tv, c2[i], ax);
 			}
 			av = wave_sum(av), aw = wave_sum(aw), ax = wave_sum(ax);
 			if (lane == 0)
@@ -216,6 +217,13 @@ namespace gple
 		{
 			__shared__ double red[4];
 			__shared__ double xj[64 * 2], bj[64];
+			// a == b: the form is symmetric — blocks above the diagonal are left to their mirror images, which count twice
+			const bool sym = a == b;
+			if (sym && blockIdx.y > blockIdx.x)
+			{
+				if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = 0.0;
+				return;
+			}
 			const int j0 = blockIdx.y * 64;
 			if (threadIdx.x < 64)
 			{
@@ -249,7 +257,7 @@ namespace gple
 				}
 			}
 			const double tot = block_sum<256>(acc, red);
-			if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+			if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = sym && blockIdx.y < blockIdx.x ? 2.0 * tot : tot;
 		}
 		__global__ void __launch_bounds__(1024) sum_kernel(const double* __restrict__ part, int n, double* __restrict__ out)
 		{
