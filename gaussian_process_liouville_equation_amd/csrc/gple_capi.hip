@@ -350,6 +350,7 @@ namespace
 			return e != nullptr && atoi(e) != 0;
 		}();
 		if (poison_t) GPLE_HIP(ctx, hipMemsetAsync(f->T, 0xFF, static_cast<size_t>(nt) * nt * 8, st));
+		if (poison_t) GPLE_HIP(ctx, hipMemsetAsync(Lbuf.p, 0xFF, static_cast<size_t>(nt + CHOL_NB) * nt * 8, st)); // likewise the working matrix above its diagonal blocks
 		// the scaled labels ride below the matrix as one more block row: its factor is u = L^-1 ys (= T ys, without the two launches)
 		const long ldl = nt + CHOL_NB;
 		GPLE_HIP(ctx, launch_gram_train(st, f->Xt, f->N, Np, nt, f->ps, Lbuf.p, ldl, f->ys));

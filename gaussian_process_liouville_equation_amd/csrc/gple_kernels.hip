@@ -91,11 +91,13 @@ namespace gple
 			}
 		}
 
-		// typed training Gram, padded with the identity
+		// typed training Gram, padded with the identity (the whole square for the getters, the lower block triangle for the factorisation)
 		// blockIdx.x == n_total / 64 (launched only when ys != nullptr): the label row below the matrix, row n_total = ys, then zeros
 		__global__ void __launch_bounds__(256) gram_train_kernel(const double* __restrict__ Xt, int N, int Np, int n_total, SEParamSet ps,
 			double* __restrict__ K, long ld, const double* __restrict__ ys)
 		{
+			// ys != nullptr: the matrix is about to be factored — only the 64-blocks on and below the diagonal are read from then on
+			if (ys != nullptr && blockIdx.y / 4 > blockIdx.x) return;
 			const int i = blockIdx.x * 64 + (threadIdx.x & 63);
 			if (i >= n_total)
 			{
