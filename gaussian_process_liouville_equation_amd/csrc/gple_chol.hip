@@ -3,8 +3,9 @@
 // Replaces the reference's Eigen::LDLT + solve(Identity) (kernel.cpp:281-283; complex_kernel.cpp:264-266).
 // The kernel matrices of this path are SPD by construction (sf^2 sn^2 ridge, opt.cpp:27), and Eigen's LDLT picks
 // its pivots from the not-yet-updated diagonal, which is constant here — i.e. the reference itself runs
-// unpivoted.  We therefore factor K = L L^T (right-looking, 64-wide panels; the diagonal blocks leave the panel step
-// already inverted), form T = L^-1 by a pairwise merge tree of MFMA GEMMs, and only on request W = K^-1 = T^T T.  A non-positive pivot does not abort: sqrt() yields
+// unpivoted.  We therefore factor K = L L^T (right-looking, 64-wide panels, one launch per panel step; the diagonal blocks leave
+// the panel step already inverted), form T = L^-1 by block rows beside the factorisation (merge trees of MFMA GEMMs over the diagonal
+// blocks, two triangular-k products per row block), and only on request W = K^-1 = T^T T.  A non-positive pivot does not abort: sqrt() yields
 // NaN which propagates into every output, and *info records the first offending column (reference behaviour:
 // LDLT::info() is never checked, NaN/Inf are clamped later by opt.cpp:420-431).
 #include <algorithm>
