@@ -861,8 +861,15 @@ namespace gple
 			hipLaunchKernelGGL((kstar_gen_kernel<0, 1>), dim3(a.m_rows / 128, ksplit), dim3(128), 0, s, a, 0, a.m_rows, Ks, mu_part, nrm_part,
 				static_cast<const int*>(nullptr), static_cast<const int*>(nullptr));
 			hipLaunchKernelGGL(compact_rows_kernel, dim3((a.m_rows + 255) / 256), dim3(256), 0, s, nrm_part, ksplit, a.m_rows, a.prune_thr, list, pos, n_live);
-			// the live rows are few: at least two groups per block make better units for the queue (2 % more work when all rows are live)
+			// the number of live row blocks is only known on the device: the finest units (most groups per block that still hold a snake pair
+			// of N-tiles each) keep the last round of the queue short whatever it turns out to be — 93 live blocks in 2 groups fill 186 of 256
+			// CUs once, in 8 groups they make 2.9 rounds of an eighth
+			static const int queue_split = [] {
+				const char* e = getenv("GPLE_PREDICT_QUEUE_SPLIT"); // 0: the split of the full launch (>= 2), as before
+				return e ? atoi(e) : ROWNORM_SPLIT_MAX;
+			}();
 			if (split < 2 && a.n_total / BN >= 4) split = 2;
+			for (int g = split * 2; g <= queue_split && 4 * g <= 2 * (a.n_total / BN); g *= 2) split = g;
 			for (int c0 = 0; c0 < a.m_rows; c0 += chunk_rows)
 			{
 				const int rows = a.m_rows - c0 < chunk_rows ? a.m_rows - c0 : chunk_rows;
