@@ -417,41 +417,41 @@ namespace gple
 			const int t = threadIdx.x, lane = t & 63;
 			const int fk = lane >> 4, fr = lane & 15;
 			const int ntiles = n_total / BN;
-			d2 areg[NA], breg[NBv];
-			auto load_ab = [&](int n0, int k0) {
-				const double* __restrict__ abase = Ks + m0 + static_cast<long>(k0) * rows;
-#pragma unroll
-				for (int qq = 0; qq < NA; ++qq)
-				{
-					const int i = t + NT * qq;
-					const int r2 = (i % (TM / 2)) * 2, k = i / (TM / 2);
-					areg[qq] = *reinterpret_cast<const d2*>(abase + r2 + static_cast<long>(k) * rows);
-				}
-				const double* __restrict__ bbase = T + n0 + static_cast<long>(k0) * ldt;
-#pragma unroll
-				for (int qq = 0; qq < NBv; ++qq)
-				{
-					const int i = t + NT * qq;
-					const int r2 = (i & 127) * 2, k = i >> 7;
-					breg[qq] = *reinterpret_cast<const d2*>(bbase + r2 + static_cast<long>(k) * ldt);
-				}
+			// Slabs go global memory -> LDS directly (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR destination).  Staged
+			// through registers (12 x 16 B per lane, written to LDS between the last MFMA and the barrier) the hand-over cost 1.1k of a k-step's
+			// 9.9k cycles with every wave of the CU standing in it at once (probes/rownorm_stamps_probe.py); the DMA lands beside the MFMAs.
+			// A wave instruction covers one k-row of the K* slab (128 doubles) or half a k-row of the T slab: contiguous in LDS, as the
+			// instruction requires (destination = wave-uniform base + 16 lane).
+			// Issued from inline asm: behind the builtin hipcc cannot tell the buffer the DMA fills from the buffer the operand reads of the
+			// step come from (same __shared__ array) and puts s_waitcnt vmcnt(0) in front of the first ds_read of every k-step — the whole
+			// DMA latency back on the critical path.  The asm form is invisible to its counters; nothing else in the k-loop touches vmcnt,
+			// and every step ends in an explicit vmcnt(0) in front of the barrier (lds_barrier_dma), so none is ever outstanding when the
+			// compiler's own memory operations run.  M0 = LDS byte address of the wave's 1 KB destination.
+			const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+			auto lds_addr = [](const double* p) { return static_cast<unsigned>(reinterpret_cast<unsigned long>((__attribute__((address_space(3))) const double*)p)); };
+			auto glds16 = [](const double* gsrc, unsigned lds_dst) {
+				unsigned keep;
+				asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+							 : "=&s"(keep)
+							 : "v"(gsrc), "s"(lds_dst)
+							 : "memory");
 			};
-			auto store_ab = [&](int buf) {
-				double* __restrict__ sa = As + buf * ASL;
+			auto lds_barrier_dma = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+			const unsigned As_addr = lds_addr(As), Bs_addr = lds_addr(Bs);
+			auto stage_ab = [&](int n0, int k0, int buf) {
+				const double* __restrict__ abase = Ks + m0 + static_cast<long>(k0) * rows + 2 * lane;
 #pragma unroll
 				for (int qq = 0; qq < NA; ++qq)
 				{
-					const int i = t + NT * qq;
-					const int r2 = (i % (TM / 2)) * 2, k = i / (TM / 2);
-					*reinterpret_cast<d2*>(sa + k * ASr + r2) = areg[qq];
+					const int k = w + (NT / 64) * qq; // i = t + NT qq, k = i / 64
+					glds16(abase + static_cast<long>(k) * rows, As_addr + 8u * static_cast<unsigned>(buf * ASL + k * ASr));
 				}
-				double* __restrict__ sb = Bs + buf * BSL;
+				const double* __restrict__ bbase = T + n0 + static_cast<long>(k0) * ldt + 128 * (w & 1) + 2 * lane;
 #pragma unroll
 				for (int qq = 0; qq < NBv; ++qq)
 				{
-					const int i = t + NT * qq;
-					const int r2 = (i & 127) * 2, k = i >> 7;
-					*reinterpret_cast<d2*>(sb + k * BS + r2) = breg[qq];
+					const int k = (w >> 1) + (NT / 128) * qq; // i = t + NT qq, k = i >> 7, columns (i & 127) * 2
+					glds16(bbase + static_cast<long>(k) * ldt, Bs_addr + 8u * static_cast<unsigned>(buf * BSL + k * BS + 128 * (w & 1)));
 				}
 			};
 			for (int jt = 0; jt < ntiles; ++jt)
@@ -465,13 +465,12 @@ namespace gple
 #pragma unroll
 					for (int j = 0; j < BF; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 				__syncthreads();
-				load_ab(n0, 0);
-				store_ab(0);
-				__syncthreads();
+				stage_ab(n0, 0, 0);
+				lds_barrier_dma();
 				// one k-step against the column blocks wn + WN t, t >= TMIN
 				auto kstep = [&](auto tmin_tag, int s) {
 					constexpr int TMIN = decltype(tmin_tag)::value;
-					if (s + 1 < nk) load_ab(n0, (s + 1) * KB);
+					if (s + 1 < nk) stage_ab(n0, (s + 1) * KB, (s + 1) & 1); // that buffer was last read in step s - 1, behind a barrier
 					const double* __restrict__ pa = As + (s & 1) * ASL + wm * (16 * AF) + fr;
 					const double* __restrict__ pb = Bs + (s & 1) * BSL + WNI * 16 + fr;
 #pragma unroll
@@ -487,8 +486,7 @@ namespace gple
 #pragma unroll
 							for (int j = TMIN; j < BF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
 					}
-					if (s + 1 < nk) store_ab((s + 1) & 1);
-					__syncthreads();
+					lds_barrier_dma(); // the DMA of this step was issued a whole step ago
 				};
 				const int nd = n0 / KB;
 				for (int s = 0; s < nd; ++s) kstep(std::integral_constant<int, 0>{}, s);
