@@ -470,17 +470,24 @@ namespace gple
 				// one k-step against the column blocks wn + WN t, t >= TMIN
 				auto kstep = [&](auto tmin_tag, int s) {
 					constexpr int TMIN = decltype(tmin_tag)::value;
-					if (s + 1 < nk) stage_ab(n0, (s + 1) * KB, (s + 1) & 1); // that buffer was last read in step s - 1, behind a barrier
 					const double* __restrict__ pa = As + (s & 1) * ASL + wm * (16 * AF) + fr;
 					const double* __restrict__ pb = Bs + (s & 1) * BSL + WNI * 16 + fr;
+					// the first group's operands are requested before the next slab's DMA goes out (that buffer was last read in step s - 1,
+					// behind a barrier): their LDS latency runs under the six DMA issues instead of after them
+					double af0[AF], bf0[BF];
+#pragma unroll
+					for (int i = 0; i < AF; ++i) af0[i] = pa[fk * ASr + i * 16];
+#pragma unroll
+					for (int j = TMIN; j < BF; ++j) bf0[j] = pb[fk * BS + j * (16 * WN)];
+					if (s + 1 < nk) stage_ab(n0, (s + 1) * KB, (s + 1) & 1);
 #pragma unroll
 					for (int kk = 0; kk < KB; kk += 4)
 					{
 						double af[AF], bf[BF];
 #pragma unroll
-						for (int i = 0; i < AF; ++i) af[i] = pa[(kk + fk) * ASr + i * 16];
+						for (int i = 0; i < AF; ++i) af[i] = kk == 0 ? af0[i] : pa[(kk + fk) * ASr + i * 16];
 #pragma unroll
-						for (int j = TMIN; j < BF; ++j) bf[j] = pb[(kk + fk) * BS + j * (16 * WN)];
+						for (int j = TMIN; j < BF; ++j) bf[j] = kk == 0 ? bf0[j] : pb[(kk + fk) * BS + j * (16 * WN)];
 #pragma unroll
 						for (int i = 0; i < AF; ++i)
 #pragma unroll
