@@ -306,7 +306,7 @@ def main():
         "config": {"workload": f"{args.workload}: N={N} samples, {G}x{G} grid (M={M}), {kernel} SE kernel, fit(error+average) + grid predict(mean,var,cutoff)",
                    "N": N, "M": M, "parallelism": (f"{world} independent density-matrix elements, one per GPU, no data-path collective" if by_element else
                                    f"grid-sharded x{world}, replicated fit, {'RCCL' if args.backend == 'nccl' else 'gloo (host)'} all-gather") if world > 1 else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": ("rownorm2_kernel<4,4,false>" if nn >= 2048 else "rownorm_kernel<8,16,false>") + " (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
+        "roofline": {"bound": "mfma", "kernel": ("rownorm2_kernel<4,4,false>" if nn >= 2048 else "rownorm2_kernel<2,8,false>") + " (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
                      "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(pk_ms, 4), "launches_per_step": launches_per_step,
                      "algorithmic_flops_per_launch": flops,

@@ -831,7 +831,7 @@ namespace gple
 			const char* e = getenv("GPLE_ROWNORM_VARIANT");
 			return e ? atoi(e) : -1;
 		}();
-		const int variant = forced >= 0 ? forced : (a.n_total / BN >= 8 ? 2 : 0);
+		const int variant = forced >= 0 ? forced : (a.n_total / BN >= 8 ? 2 : 3); // with the LDS-DMA staging the 2 x 8 blocking leads below eight N-tiles (C2: 64.3 vs 62.9 / 61.2 TFLOP/s)
 		double* Ks = scratch;
 		double* mu_part = scratch + static_cast<size_t>(chunk_rows) * a.n_total;
 		const bool small = few_rows && chunk_rows == a.m_rows;
