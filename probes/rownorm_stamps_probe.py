@@ -1,3 +1,7 @@
+"""Cycle stamps inside rownorm2_kernel (wave 0 of workgroup 0: k-step entry and the point after the step's last MFMA) at C4r: how long a k-step takes
+against its 8192 cycles of MFMA time, and where the rest goes.  Needs the instrumented build: `git apply probes/rownorm_stamps.patch && make -C
+gaussian_process_liouville_equation_amd/csrc` (adds two __device__ stamp stores per k-step and gple_debug_rownorm_stamps; revert afterwards — the stamp
+stores cost ~600 cycles per step themselves, so read differences between variants, not absolute periods)."""
 import ctypes, os, sys, json
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
