@@ -2214,6 +2214,20 @@ extern "C"
 		return GPLE_OK;
 	}
 
+	/* gple_debug.h: the layout the factorisation of an n-column matrix will use (host logic only, no device call): outer block bounds
+	 * (0 … n), fork points of the block-row inverse, workspace doubles.  Arrays of `cap` ints; counts come back in nb / nf. */
+	int gple_debug_chol_layout(int n, int cap, int* bounds, int* nb, int* forks, int* nf, unsigned long long* work_doubles)
+	{
+		if (n <= 0 || n % 64 || !bounds || !nb || !forks || !nf || !work_doubles) return GPLE_ERR_BAD_ARG;
+		std::vector<int> b, f;
+		size_t w = 0;
+		chol_layout(n, b, f, w);
+		if (static_cast<int>(b.size()) > cap || static_cast<int>(f.size()) > cap) return GPLE_ERR_BAD_ARG;
+		std::copy(b.begin(), b.end(), bounds), std::copy(f.begin(), f.end(), forks);
+		*nb = static_cast<int>(b.size()), *nf = static_cast<int>(f.size()), *work_doubles = w;
+		return GPLE_OK;
+	}
+
 	/* gple_debug.h: instrumented launches of the one-launch panel step (potrf_step_kernel) at block column 1 of an n x n matrix,
 	 * n = 128 + below (below = 0 | 64), column-major on the host, overwritten with what the first launch leaves; T (n x n) likewise. */
 	int gple_debug_potrf_step(gple_ctx* ctx, double* A, double* T, int pend, int below, long long* stamps, int reps, float* ms_per_launch)

@@ -1118,6 +1118,15 @@ namespace gple
 		return t_product(s, done, n);
 	}
 
+	// host-only view of the factorisation's layout for n columns (tests/test_host_logic.py through gple_debug_chol_layout): outer block
+	// bounds, fork points of the inverse, workspace doubles
+	void chol_layout(int n, std::vector<int>& bounds, std::vector<int>& forks, size_t& work_doubles)
+	{
+		bounds = chol_block_bounds(n);
+		forks = n >= chol_overlap_min_n() && n / NB >= 4 ? chol_fork_points(n) : std::vector<int>{};
+		work_doubles = chol_inverse_work_doubles(n);
+	}
+
 	hipError_t lauum_full(hipStream_t s, const double* T, long ldt, double* W, long ldw, int n)
 	{
 		GemmDesc g{};

@@ -2,6 +2,7 @@
  * internal kernel family on host operands so that tests and probes can check it in isolation.
  *   tests/test_gpu_chol_diag.py, probes/diag_probe.py -> gple_debug_potrf_diag
  *   tests/test_gpu_chol_diag.py, probes/step_probe.py -> gple_debug_potrf_step
+ *   tests/test_host_logic.py                          -> gple_debug_chol_layout (no device call)
  *   tests/test_gpu_gemm.py                            -> gple_debug_gemm */
 #ifndef GPLE_DEBUG_H
 #define GPLE_DEBUG_H
@@ -14,6 +15,8 @@ extern "C"
 	 * A: 64 x 64 column-major SPD block; T out: inv(chol(A)); stamps: 16 shader-clock stamps of the kernel's stages;
 	 * ms_per_launch: average over `reps` back-to-back launches. */
 	int gple_debug_potrf_diag(gple_ctx* ctx, const double* A, double* T, long long* stamps, int reps, float* ms_per_launch);
+	/* Layout of the factorisation of an n-column matrix (host logic only): outer block bounds, fork points of the block-row inverse, workspace. */
+	int gple_debug_chol_layout(int n, int cap, int* bounds, int* nb, int* forks, int* nf, unsigned long long* work_doubles);
 	/* The one-launch panel step (potrf_step_kernel) at block column 1 of an n x n matrix, n = 128 + below (below = 0 | 64); A and T
 	 * (n x n, column-major) come back as the first launch leaves them; stamps: 24 slots — shader-clock stamps of workgroup 0, the last slot = `info` (0, or 1 + the first column whose pivot was not positive). */
 	int gple_debug_potrf_step(gple_ctx* ctx, double* A, double* T, int pend, int below, long long* stamps, int reps, float* ms_per_launch);

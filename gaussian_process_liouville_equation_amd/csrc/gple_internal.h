@@ -149,6 +149,7 @@ namespace gple
 	// first non-positive pivot.
 	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec = nullptr);
 	hipError_t debug_potrf_diag(hipStream_t s, const double* A, double* T, int* info, long long* stamps);
+	void chol_layout(int n, std::vector<int>& bounds, std::vector<int>& forks, size_t& work_doubles);
 	hipError_t debug_potrf_step(hipStream_t s, double* A, long lda, double* T, long ldt, int* info, long long* stamps, int pend, int below);
 	// Completes T = L^-1 (lower) given its diagonal blocks; work: at least n*n/4 doubles.
 	hipError_t trtri_lower_from_diag(hipStream_t s, const double* L, long ldl, double* T, long ldt, int n, double* work);

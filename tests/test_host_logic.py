@@ -240,3 +240,41 @@ def test_average_point_and_logging_writers(oracle):
     output.output_logging(lg, 12.5, (0.0123, [5, 6, 7, 8, 9], 2), {e: (200, 1.0) for e in dens}, 3.25, ks)
     parts = lg.getvalue().split()
     assert parts[0] == "12.5" and parts[1] == "3.25" and parts[2:5] == ["200"] * 3 and parts[5:8] == ["1"] * 3 and len(parts) >= 2 + 6 + 3 + 1 + 5 + 1 + 2
+
+
+def test_factorisation_layout_rules():
+    """csrc/gple_chol.hip, host logic only (gple_debug_chol_layout makes no device call): the outer blocks of the Cholesky (sized by a tile
+    budget per launch) and the fork points of the block-row inverse for every padded size a fit can have — ascending multiples of 64 from 0
+    to n, no block or row group narrower than 256 columns, forks only from n = 1024 on, workspace large enough for what chol_inverse_factor
+    carves out of it (W <= n^2 / 4, two merge trees)"""
+    import ctypes
+    import gaussian_process_liouville_equation_amd as pkg
+    lib = pkg.load_library()
+    lib.gple_debug_chol_layout.restype = ctypes.c_int
+    cap = 512
+    b, f = (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+    nb, nf, wd = ctypes.c_int(), ctypes.c_int(), ctypes.c_ulonglong()
+    assert lib.gple_debug_chol_layout(100, cap, b, ctypes.byref(nb), f, ctypes.byref(nf), ctypes.byref(wd)) != 0  # not a multiple of 64
+    for n in list(range(256, 8192 + 1, 256)) + [12288, 16384]:
+        assert lib.gple_debug_chol_layout(n, cap, b, ctypes.byref(nb), f, ctypes.byref(nf), ctypes.byref(wd)) == 0
+        bounds, forks = list(b[:nb.value]), list(f[:nf.value])
+        assert bounds[0] == 0 and bounds[-1] == n and all(x % 64 == 0 for x in bounds)
+        widths = np.diff(bounds)
+        assert np.all(widths >= 256) or len(bounds) == 2
+        if n <= 2304:
+            assert len(bounds) == 2  # one block: every strip fits the side workgroups of a launch
+        if n >= 4096:
+            assert len(bounds) > 2 and np.all(np.diff(widths[:-1]) >= 0)  # the blocks widen as the trailing matrix shrinks
+        assert (len(forks) == 0) == (n < 1024)
+        edges = [0] + forks + [n]
+        assert all(x % 64 == 0 for x in forks) and np.all(np.diff(edges) >= 256)
+        # chol_inverse_factor's carve-up of the workspace: [0, q) W of a row block, [q, 2q) the side stream's merge tree, [2q, 2q + q/4) the main
+        # stream's (q = n^2 / 4); without forks one merge tree over all n columns (n^2 / 4)
+        groups = [int(g) for g in np.diff(edges)]
+        q = n * n // 4
+        if forks:
+            assert max(w * e for w, e in zip(groups, edges[:-1])) <= q
+            assert max(g * g // 4 for g in groups[:-1]) <= q and groups[-1] ** 2 // 4 <= q // 4
+            assert wd.value >= 2 * q + q // 4
+        else:
+            assert wd.value >= q
