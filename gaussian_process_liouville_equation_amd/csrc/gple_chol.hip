@@ -1000,7 +1000,7 @@ namespace gple
 	// T(g, 0..g0) = -T_gg (L(g, 0..g0) T(0..g0, 0..g0)), two triangular-k GEMMs — so the side stream of the context works through the row
 	// blocks while the main stream keeps factoring, and only the last row block is left when the last panel is done.  The first form of
 	// this (one split in the middle, both halves' trees + a 2048-wide join after the last panel at n = 4096) left 0.5 ms behind the last
-	// panel; the work of a row block grows with g0^2, so the groups shrink towards the end: fork points at 60 % and 80 % of n
+	// panel; the work of a row block grows with g0^2, so the groups shrink towards the end: fork points at 60 % and 80 % of n, from n = 8192 on also at 90 %
 	// (GPLE_CHOL_FORKS = comma-separated percentages for A/B runs), none closer than 256 columns to its neighbours.
 	static const std::vector<int>& chol_fork_points(int n)
 	{
@@ -1024,8 +1024,10 @@ namespace gple
 		auto it = cache.find(n);
 		if (it != cache.end()) return it->second;
 		std::vector<int> f;
+		std::vector<int> use = pct;
+		if (getenv("GPLE_CHOL_FORKS") == nullptr && n >= 8192) use.push_back(90); // a third, late fork pays from here on (9.20 vs 9.34 ms at n = 8192)
 		int next = n; // from the last one down: the late fork matters most
-		for (auto it2 = pct.rbegin(); it2 != pct.rend(); ++it2)
+		for (auto it2 = use.rbegin(); it2 != use.rend(); ++it2)
 		{
 			const int j = static_cast<int>(static_cast<long>(n) * *it2 / 100) / NB * NB;
 			if (*it2 <= 0 || *it2 >= 100 || next - j < 256 || j < 256) continue;
