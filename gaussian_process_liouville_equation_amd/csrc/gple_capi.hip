@@ -1592,7 +1592,13 @@ extern "C"
 		{
 			if (allgather_fn o = allgather_override.load()) return o;
 			static allgather_fn fn = [] {
-				void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+				void* sym = nullptr;
+				if (const char* named = getenv("GPLE_RCCL_LIBRARY")) // the caller names the library its ncclComm_t comes from: nothing else is tried
+				{
+					if (void* h = dlopen(named, RTLD_NOW | RTLD_GLOBAL)) sym = dlsym(h, "ncclAllGather");
+					return reinterpret_cast<allgather_fn>(sym);
+				}
+				sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
 				if (!sym)
 					for (const char* name : {"librccl.so.1", "librccl.so"})
 						if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))
@@ -1646,7 +1652,8 @@ extern "C"
 		if (!allgather)
 		{
 			std::lock_guard<std::mutex> lk(ctx->mu);
-			ctx->last_error = std::string("ncclAllGather not found: ") + (dlerror() ? dlerror() : "librccl is not loadable");
+			const char* de = dlerror(); // one call: dlerror() clears the state it returns
+			ctx->last_error = std::string("ncclAllGather not found: ") + (de ? de : "librccl is not loadable");
 			return GPLE_ERR_COLLECTIVE;
 		}
 		// this rank's points: the 128-point blocks rank, rank + world, ... (the last block of the set may be short)
@@ -1678,9 +1685,21 @@ extern "C"
 				GPLE_HIP(ctx, hipGetLastError());
 			}
 		}
+		// A rank whose own predict fails still enters the collective (with whatever its buffer holds: the other ranks get their
+		// result, this one reports its error afterwards) -- returning here would leave every other rank waiting in ncclAllGather.
+		// Only a failure to allocate the collective's own buffers above returns early; the caller then has to abort the communicator.
+		int rc_local = GPLE_OK;
+		std::string err_local;
 		if (n_local)
-			GPLE_TRY(predict_common(ctx, f, xs.p, n_local, GPLE_IO_DEVICE | (flags & GPLE_PREDICT_FULL), nullptr, local.p, local.p + ow * per, local.p + (ow + 1) * per,
-				nullptr));
+		{
+			rc_local = predict_common(ctx, f, xs.p, n_local, GPLE_IO_DEVICE | (flags & GPLE_PREDICT_FULL), nullptr, local.p, local.p + ow * per,
+				local.p + (ow + 1) * per, nullptr);
+			if (rc_local != GPLE_OK)
+			{
+				std::lock_guard<std::mutex> l2(ctx->mu);
+				err_local = ctx->last_error;
+			}
+		}
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
 		const int rc = allgather(local.p, gathered.p, blk, /* ncclDouble */ 8, comm, st);
@@ -1689,6 +1708,13 @@ extern "C"
 			std::lock_guard<std::mutex> l2(ctx->mu);
 			ctx->last_error = "ncclAllGather returned " + std::to_string(rc);
 			return GPLE_ERR_COLLECTIVE;
+		}
+		if (rc_local != GPLE_OK)
+		{
+			GPLE_HIP(ctx, hipStreamSynchronize(st)); // the scratch buffers go back to the pool when this returns
+			std::lock_guard<std::mutex> l2(ctx->mu);
+			ctx->last_error = err_local;
+			return rc_local;
 		}
 		double *d_mean = prediction, *d_var = variance, *d_cut = cutoff_prediction;
 		if (!dev)

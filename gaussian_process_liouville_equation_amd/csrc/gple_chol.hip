@@ -935,7 +935,7 @@ namespace gple
 		return hipGetLastError();
 	}
 
-	hipError_t trtri_lower_from_diag(hipStream_t s, const double* L, long ldl, double* T, long ldt, int n, double* work)
+	hipError_t trtri_lower_from_diag(hipStream_t s, const double* L, long ldl, double* T, long ldt, int n, double* work, int origin)
 	{
 		struct Blk
 		{
@@ -968,7 +968,8 @@ namespace gple
 				g.C = work, g.ldc = s2, g.strideC = static_cast<long>(s1) * s2;
 				g.M = s2, g.N = s1, g.K = s1, g.batch = count, g.alpha = 1.0, g.beta = 0.0;
 				g.krange = K_GE_N, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
-				const int tile = gemm_pick_tile(s2, s1, count, true);
+				int tile = gemm_pick_tile(s2, s1, count, true);
+				if (tile == 128 && (origin + start) % 128) tile = 64; // see tri_tile
 				hipError_t e = launch_gemm(s, g, tile);
 				if (e != hipSuccess) return e;
 				// T21_b = - T22_b * W_b
@@ -1035,11 +1036,45 @@ namespace gple
 		}
 		return cache.emplace(n, std::move(f)).first->second;
 	}
+	// Workspace of chol_inverse_factor, from the fork list actually in use (GPLE_CHOL_FORKS may put the forks anywhere): W = L(g, 0..g0) T(0..g0)
+	// of the widest row block product, the merge tree of the widest side job, the merge tree of the last row block (a tree over b columns needs
+	// b^2 / 4 doubles: count * s1 * s2 per level); the unsplit path uses one tree of n^2 / 4 at the front
+	struct InvWork
+	{
+		size_t prod, side, main;
+	};
+	static InvWork chol_inverse_work_split(int n)
+	{
+		const auto sq4 = [](size_t b) { return b * b / 4; };
+		InvWork w{0, 0, 0};
+		const std::vector<int>& forks = chol_fork_points(n);
+		if (n < chol_overlap_min_n() || n / NB < 4 || forks.empty())
+		{
+			w.prod = sq4(static_cast<size_t>(n));
+			return w;
+		}
+		size_t done = 0;
+		for (int j : forks)
+		{
+			w.side = std::max(w.side, sq4(static_cast<size_t>(j) - done));
+			w.prod = std::max(w.prod, (static_cast<size_t>(j) - done) * done);
+			done = static_cast<size_t>(j);
+		}
+		w.prod = std::max(w.prod, (static_cast<size_t>(n) - done) * done);
+		w.main = sq4(static_cast<size_t>(n) - done);
+		return w;
+	}
 	size_t chol_inverse_work_doubles(int n)
 	{
-		// W = L(g, 0..g0) T(0..g0) of a row block: <= n^2 / 4; merge trees of the side and of the main stream: <= n^2 / 4 (the unsplit path) and n^2 / 16
-		const size_t q = static_cast<size_t>(n) * static_cast<size_t>(n) / 4;
-		return q + q + q / 4 + 64;
+		const InvWork w = chol_inverse_work_split(n);
+		return w.prod + w.side + w.main + 64;
+	}
+	// 128-tile GEMMs with a triangular k-range start at their 128-aligned diagonal tile and take in the block above the second 64-block of the
+	// pair, which the panel step zeroes for GLOBALLY odd 64-blocks only: a sub-matrix whose origin is an odd multiple of 64 stays on 64-tiles
+	static int tri_tile(long m, long ncols, long batch, int origin)
+	{
+		const int t = gemm_pick_tile(m, ncols, batch, true);
+		return t == 128 && origin % 128 ? 64 : t;
 	}
 	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work, double* uvec)
 	{
@@ -1072,27 +1107,27 @@ namespace gple
 			ctx->side_forks.push_back(ev);
 		}
 		hipStream_t side = ctx->side_stream;
-		const size_t q = static_cast<size_t>(n) * static_cast<size_t>(n) / 4;
-		double* w_prod = work;          // W of the row block in flight (side jobs are serial; the last one runs after the join)
-		double* w_side = work + q;      // merge tree of a side job
-		double* w_main = work + 2 * q;  // merge tree of the last row block (main stream, beside the side's last job)
+		const InvWork iw = chol_inverse_work_split(n);
+		double* w_prod = work;                     // W of the row block in flight (side jobs are serial; the last one runs after the join)
+		double* w_side = work + iw.prod;           // merge tree of a side job
+		double* w_main = work + iw.prod + iw.side; // merge tree of the last row block (main stream, beside the side's last job)
 		// row block [g0, g1) of T: its diagonal block by the merge tree, W = L(g, 0..g0) T(0..g0, 0..g0), T(g, 0..g0) = -T_gg W
 		auto tree = [&](hipStream_t st, int g0, int g1, double* w_tree) -> hipError_t {
-			return trtri_lower_from_diag(st, A + g0 + static_cast<long>(g0) * lda, lda, T + g0 + static_cast<long>(g0) * ldt, ldt, g1 - g0, w_tree);
+			return trtri_lower_from_diag(st, A + g0 + static_cast<long>(g0) * lda, lda, T + g0 + static_cast<long>(g0) * ldt, ldt, g1 - g0, w_tree, g0);
 		};
 		auto w_product = [&](hipStream_t st, int g0, int g1) -> hipError_t {
 			GemmDesc g{};
 			g.A = A + g0, g.lda = lda, g.B = T, g.ldb = ldt, g.C = w_prod, g.ldc = g1 - g0;
 			g.M = g1 - g0, g.N = g0, g.K = g0, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
 			g.krange = K_GE_N, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
-			return launch_gemm(st, g, gemm_pick_tile(g1 - g0, g0, 1, true));
+			return launch_gemm(st, g, tri_tile(g1 - g0, g0, 1, g0));
 		};
 		auto t_product = [&](hipStream_t st, int g0, int g1) -> hipError_t {
 			GemmDesc g{};
 			g.A = T + g0 + static_cast<long>(g0) * ldt, g.lda = ldt, g.B = w_prod, g.ldb = g1 - g0, g.C = T + g0, g.ldc = ldt;
 			g.M = g1 - g0, g.N = g0, g.K = g1 - g0, g.batch = 1, g.alpha = -1.0, g.beta = 0.0;
 			g.krange = K_LE_M, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
-			return launch_gemm(st, g, gemm_pick_tile(g1 - g0, g0, 1, true));
+			return launch_gemm(st, g, tri_tile(g1 - g0, g0, 1, g0));
 		};
 		int done = 0;
 		size_t nfork = 0;

@@ -152,7 +152,7 @@ namespace gple
 	void chol_layout(int n, std::vector<int>& bounds, std::vector<int>& forks, size_t& work_doubles);
 	hipError_t debug_potrf_step(hipStream_t s, double* A, long lda, double* T, long ldt, int* info, long long* stamps, int pend, int below);
 	// Completes T = L^-1 (lower) given its diagonal blocks; work: at least n*n/4 doubles.
-	hipError_t trtri_lower_from_diag(hipStream_t s, const double* L, long ldl, double* T, long ldt, int n, double* work);
+	hipError_t trtri_lower_from_diag(hipStream_t s, const double* L, long ldl, double* T, long ldt, int n, double* work, int origin = 0); // origin: global column of L(0,0) (128-tile rule)
 	// L = chol(A) and T = L^-1 in one go (what a fit needs): potrf_lower + trtri_lower_from_diag, with the inverse of the
 	// leading half (its merge tree and the first GEMM of the last merge, more than half of the tree's work) running on the
 	// context's side stream while the main stream factors the trailing half.  work: chol_inverse_work_doubles(n) doubles.

@@ -119,3 +119,34 @@ def test_sharded_predict_between_threads(gpu, world, cplx):
             assert np.array_equal(mean, ref["prediction"]) and np.array_equal(var, ref["variance"]) and np.array_equal(cut, ref["cutoff"])
     finally:
         gpu.lib.gple_set_allgather_function(None)
+
+
+def test_sharded_predict_without_rccl_reports_a_collective_error():
+    """world > 1, no transport plugged in and no loadable librccl: GPLE_ERR_COLLECTIVE with a message, not a crash (the branch used to
+    build its message from a second dlerror() call, which returns NULL).  Own process: the resolved entry point is cached per process."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+import gaussian_process_liouville_equation_amd as pkg
+from tests import parity
+api = pkg.open_api(0)
+X, y, Xs = parity.synthetic_real(64, 300, 3)
+fit = api.real_fit([1.0, 0.7086, 0.7056, 1e-2], X, y, 0)
+dp = C.POINTER(C.c_double)
+fn = api.lib.gple_real_predict_sharded
+fn.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_size_t, C.c_uint, C.c_int, C.c_int, C.c_void_p, dp, dp, dp]
+out = np.empty(300)
+st = fn(api.ctx, fit.handle, np.ascontiguousarray(Xs).ctypes.data_as(dp), 300, 0, 0, 2, C.c_void_p(1), out.ctypes.data_as(dp), None, None)
+api.lib.gple_ctx_last_error.restype = C.c_char_p
+api.lib.gple_ctx_last_error.argtypes = [C.c_void_p]
+msg = api.lib.gple_ctx_last_error(api.ctx)
+print("STATUS", st, msg.decode())
+''' % ROOT
+    env = dict(os.environ, GPLE_RCCL_LIBRARY="/nonexistent/librccl.so.1")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("STATUS")][0].split(" ", 2)
+    assert int(line[1]) == 5, res.stdout  # GPLE_ERR_COLLECTIVE (include/gple.h)
+    assert "ncclAllGather not found" in line[2] and len(line[2]) > len("ncclAllGather not found: ")

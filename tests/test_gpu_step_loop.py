@@ -125,7 +125,7 @@ def test_tick_mirror_and_phase_files(gpu, oracle):
         output.output_phase(ph, va, ks, grid)
         files[name] = (ph.getvalue(), va.getvalue())
     for a, b in zip(files["gpu"], files["oracle"]):
-        la, lb = a.split("\\n"), b.split("\\n")
+        la, lb = a.split("\n"), b.split("\n")
         assert len(la) == len(lb)
         for x, y in zip(la, lb):
             assert len(x.split()) == len(y.split())

@@ -1,13 +1,15 @@
 """CPU: the Python mirror of the reference interface (kernels.py) driven through the oracle binding — class names, getters,
 assert-style errors, TrainingKernels aggregation, parameter packing, log-reparametrisation and make_normal."""
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
 
 from gaussian_process_liouville_equation_amd import kernels as K
 from tests import parity
-from tests.conftest import load_golden
+from tests.conftest import ROOT, load_golden
 
 
 def test_training_and_predictive_kernel_getters(oracle):
@@ -268,13 +270,34 @@ def test_factorisation_layout_rules():
         assert (len(forks) == 0) == (n < 1024)
         edges = [0] + forks + [n]
         assert all(x % 64 == 0 for x in forks) and np.all(np.diff(edges) >= 256)
-        # chol_inverse_factor's carve-up of the workspace: [0, q) W of a row block, [q, 2q) the side stream's merge tree, [2q, 2q + q/4) the main
-        # stream's (q = n^2 / 4); without forks one merge tree over all n columns (n^2 / 4)
+        # chol_inverse_factor's carve-up of the workspace follows the fork list: W of the widest row-block product, the widest side job's merge tree,
+        # the last row block's merge tree (b^2 / 4 doubles for b columns); without forks one merge tree over all n columns
         groups = [int(g) for g in np.diff(edges)]
-        q = n * n // 4
         if forks:
-            assert max(w * e for w, e in zip(groups, edges[:-1])) <= q
-            assert max(g * g // 4 for g in groups[:-1]) <= q and groups[-1] ** 2 // 4 <= q // 4
-            assert wd.value >= 2 * q + q // 4
+            need = max(w * e for w, e in zip(groups, edges[:-1])) + max(g * g // 4 for g in groups[:-1]) + groups[-1] ** 2 // 4
+            assert wd.value >= need
         else:
-            assert wd.value >= q
+            assert wd.value >= n * n // 4
+
+
+def test_factorisation_layout_with_forced_forks():
+    """GPLE_CHOL_FORKS may put the forks anywhere (read once per process: own process): a single early fork leaves a last row block of 0.7 n whose
+    merge tree needs 0.12 n^2 doubles — the workspace is sized from the fork list in use, not from the default list's bounds"""
+    import subprocess
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+import gaussian_process_liouville_equation_amd as pkg
+lib = pkg.load_library()
+b, f = (ctypes.c_int * 512)(), (ctypes.c_int * 512)()
+nb, nf, wd = ctypes.c_int(), ctypes.c_int(), ctypes.c_ulonglong()
+for n in (1024, 4096, 8192):
+    assert lib.gple_debug_chol_layout(n, 512, b, ctypes.byref(nb), f, ctypes.byref(nf), ctypes.byref(wd)) == 0
+    forks = list(f[:nf.value])
+    assert len(forks) == 1 and abs(forks[0] - 0.3 * n) <= 64, forks
+    last = n - forks[0]
+    assert wd.value >= last * forks[0] + forks[0] ** 2 // 4 + last ** 2 // 4, (n, wd.value)
+print("ok")
+''' % ROOT
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPLE_CHOL_FORKS="30"), capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-2000:]
