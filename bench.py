@@ -32,12 +32,16 @@ WORKLOADS = {  # name: (N, G, kernel)
     "C4r": (4096, 512, "real"),     # one real element of configs[3] = the north-star target size: the default
     "C4c": (4096, 512, "complex"),  # the complex element of C4
     "C5r": (8192, 1024, "real"),    # one real element of C5
+    "C4": (4096, 512, "elements2"),  # configs[3] whole: the 3 elements of a 2-state density matrix (real, complex, real), hybrid element x grid plan
+    "C5": (8192, 1024, "elements3"), # configs[4]'s GP side: the 6 elements of a 3-state density matrix (3 real + 3 complex)
     "C4opt": (4096, 0, "opt"),      # the opt.cpp loop of configs[3]: 2 real + 1 complex objective evaluations with gradient
     "C2step": (1024, 0, "step"),    # one tick of main.cpp:143-176 at N = 1024: evolve density + 5N extra points, refit 3 elements
     "C5step": (8192, 0, "step"),    # the same at the N of configs[4] (two-level physics: what the reference instantiates)
 }
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak; measured 78.4 with v_mfma_f64_16x16x4_f64
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+# density-matrix elements in the reference's order (lower triangle, row-major: storage.h / predict.cpp:290-360)
+ELEMENT_KINDS = {"elements2": ["real", "complex", "real"], "elements3": ["real", "complex", "real", "complex", "complex", "real"]}
 
 
 def synthetic(N, G, seed, kernel="real"):
@@ -141,6 +145,49 @@ def cpu_baseline(workload, N, G, kernel, X, y, grid, theta, runs=3):
                       f"({tf:.2f} s) + predict on {m_s} of {M} grid points scaled to M ({tp:.2f} s); workload {workload}"}
 
 
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+_RCCL = {}
+
+
+def make_rccl_comm(torch, dist, rank, world):
+    """An ncclComm_t over all ranks for the library's own collective (gple_*_predict_sharded / _dealt): rank 0 draws the unique id, the 128
+    bytes travel over torch.distributed's control group, every rank joins with ncclCommInitRank on its current device.  librccl is loaded
+    RTLD_GLOBAL — torch's own copy when it ships one, so that the process holds ONE RCCL — and libgple_hip.so finds ncclAllGather in the
+    process image, i.e. in the library this communicator belongs to."""
+    cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"]
+    path = next((q for q in cands if os.path.exists(q)), "librccl.so.1")
+    rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    rccl.ncclGetErrorString.restype = C.c_char_p
+    uid = _NcclUniqueId()
+    if rank == 0:
+        rc = rccl.ncclGetUniqueId(C.byref(uid))
+        if rc != 0:
+            raise RuntimeError(f"ncclGetUniqueId: {rccl.ncclGetErrorString(rc).decode()}")
+    if world > 1:
+        buf = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+        if dist.get_backend() == "nccl":
+            buf = buf.cuda()
+        dist.broadcast(buf, 0)
+        C.memmove(C.byref(uid), bytes(buf.cpu().numpy().tobytes()), 128)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+    rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError(f"ncclCommInitRank(rank {rank} of {world}): {rccl.ncclGetErrorString(rc).decode()}")
+    _RCCL["lib"] = rccl
+    return comm, path
+
+
+def destroy_rccl_comm(comm):
+    rccl = _RCCL.get("lib")
+    if rccl is not None and comm:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +200,13 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1: nccl (= RCCL over xGMI, the default) or gloo (rehearsal of the "
                          "multi-rank path on fewer GPUs than ranks; ranks then share devices and gather through host memory)")
+    ap.add_argument("--via", default=None, choices=["capi", "torch"],
+                    help="--gpus > 1, who gathers the grid: 'capi' (default with the nccl backend) = the product's own entry point, "
+                         "gple_*_predict_sharded / _dealt with an ncclComm_t created here from librccl (what a C++ output_phase calls; "
+                         "torch.distributed then only carries the 128-byte unique id, the barriers and the timing reduction, over gloo); "
+                         "'torch' = parallel.GridShardedStep with torch.distributed.all_gather_into_tensor (the A/B, and the gloo rehearsal)")
+    ap.add_argument("--comm-at-one", action="store_true", help="--gpus 1 --via capi: still create a one-rank ncclComm_t and go through the all-gather path")
+    ap.add_argument("--plan", default="auto", choices=["auto", "elements", "grid", "hybrid"], help="--workload C4 | C5: force one of the planner's candidates")
     ap.add_argument("--shard", default="grid", choices=["grid", "elements"],
                     help="--gpus > 1: 'grid' (default) = strong scaling of ONE element's step, the grid prediction split over the "
                          "ranks and all-gathered; 'elements' = weak scaling over the independent density-matrix elements, every "
@@ -173,11 +227,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
     torch.cuda.set_device(dev)
+    multi = WORKLOADS[args.workload][2] in ELEMENT_KINDS
+    grid_wl = WORKLOADS[args.workload][2] in ("real", "complex")
+    if args.via is None:
+        args.via = "capi" if (args.backend == "nccl" and (multi or (grid_wl and args.shard == "grid"))) else "torch"
+    if args.via == "capi" and not (multi or grid_wl):
+        raise SystemExit("--via capi applies to the grid-predict workloads (C1 ... C5r, C4, C5)")
+    if args.via == "capi" and args.backend == "gloo":
+        raise SystemExit("--via capi gathers with RCCL inside the library; the gloo rehearsal is --via torch")
+    args.control = "gloo" if (args.via == "capi" or args.backend == "gloo") else "nccl"  # who carries barriers and the timing reduction
     if world > 1:
-        if args.backend == "nccl":
+        if args.control == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group("gloo")
+    if multi:
+        return elements_step(args, pkg, c, parallel, torch, dist, rank, world, dev)
     if args.workload == "C4opt":
         return opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev)
     if WORKLOADS[args.workload][2] == "step":
@@ -208,6 +273,16 @@ def main():
     shard = parallel.GridShardedStep(M, rows, alloc, via_host=args.backend == "gloo", shard=not by_element, cyclic=args.prune and not cplx)
     lo, hi = shard.lo, shard.hi
     dgrid_mine = dgrid_all[shard.idx.to(dgrid_all.device)].contiguous() if shard.cyclic else None
+    # --via capi: the product's own collective.  One ncclComm_t per process from the librccl of this process; the library resolves
+    # ncclAllGather from the process image, i.e. from the same library.
+    capi = args.via == "capi" and not by_element and (world > 1 or args.comm_at_one)
+    comm, via_note = None, ("torch.distributed all_gather_into_tensor" if world > 1 else "no collective (one rank)")
+    if capi:
+        comm, rccl_path = make_rccl_comm(torch, dist, rank, world)
+        via_note = f"gple_{'complex' if cplx else 'real'}_predict_sharded: ncclAllGather inside the library ({rccl_path}), block-cyclic deal of 128-point blocks"
+        full_out = torch.empty(rows, M, dtype=torch.float64, device="cuda")
+        pts_mine, _ = parallel.deal_shares(M, [1] * world)
+        lo, hi = 0, pts_mine[rank]  # the rank's number of points (for the flop count below)
 
     def fit():
         h = C.c_void_p()
@@ -234,8 +309,21 @@ def main():
     # below and reported as "pruned", so that `value` and `roofline` keep pricing the full N(N+1) flops per grid point
     predict_mode = {"flag": 0 if args.prune else c.PREDICT_FULL}
 
+    def predict_capi(h):
+        o_mean, o_var, o_cut = (full_out[0:2], full_out[2], full_out[3:5]) if cplx else (full_out[0], full_out[1], full_out[2])
+        fn = api.lib.gple_complex_predict_sharded if cplx else api.lib.gple_real_predict_sharded
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_uint, C.c_int, C.c_int, C.c_void_p] + [C.POINTER(C.c_double)] * 3
+        st = fn(api.ctx, h, dp(dgrid_all), M, c.IO_DEVICE | predict_mode["flag"], rank, world, comm, dp(o_mean), dp(o_var), dp(o_cut))
+        if st != 0:
+            raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
+
     def step():
-        h, full = shard.run(fit, predict_slice)  # fit + this rank's slice + all-gather (RCCL on the same stream as the kernels)
+        if capi:
+            h = fit()
+            predict_capi(h)  # this rank's blocks + ncclAllGather + unpack, all enqueued on the context's stream
+            full = full_out
+        else:
+            h, full = shard.run(fit, predict_slice)  # fit + this rank's slice + all-gather (RCCL on the same stream as the kernels)
         last["full"] = full
         # the fit's scalar members (error, population, <r>, purity): the one host synchronisation of the step; fit and
         # predict above only enqueue
@@ -259,7 +347,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.control == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # sanity of the (gathered) grid: every rank must now hold all M points (checked once, outside the timed region)
@@ -305,7 +393,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: N={N} samples, {G}x{G} grid (M={M}), {kernel} SE kernel, fit(error+average) + grid predict(mean,var,cutoff)",
                    "N": N, "M": M, "parallelism": (f"{world} independent density-matrix elements, one per GPU, no data-path collective" if by_element else
-                                   f"grid-sharded x{world}, replicated fit, {'RCCL' if args.backend == 'nccl' else 'gloo (host)'} all-gather") if world > 1 else "single GPU"},
+                                   f"grid-sharded x{world}, replicated fit, {'RCCL' if args.backend == 'nccl' else 'gloo (host)'} all-gather") if world > 1 else "single GPU",
+                   "via": args.via, "collective": via_note},
         "roofline": {"bound": "mfma", "kernel": ("rownorm2_kernel<4,4,false>" if nn >= 2048 else "rownorm2_kernel<2,8,false>") + " (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
                      "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(pk_ms, 4), "launches_per_step": launches_per_step,
@@ -349,6 +438,178 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args.workload, N, G, kernel, X, y, grid, theta)
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if comm is not None:
+        destroy_rccl_comm(comm)
+    api.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def elements_step(args, pkg, c, parallel, torch, dist, rank, world, dev):
+    """--workload C4 | C5: one step = fit(error + averages) + full-grid predict of EVERY element of the density matrix (predict.cpp:390-393 +
+    output.cpp:181-233: 2 real + 1 complex at NumPES = 2, 3 + 3 at NumPES = 3), the elements spread over the ranks by parallel.plan_elements
+    (whole elements, everyone's grid split over everyone, or equal-time stretches) and every element's grid gathered on every rank by the
+    library's weighted deal (gple_*_predict_dealt, RCCL inside) or, --via torch, by parallel.gather_dealt."""
+    N, G, tag = WORKLOADS[args.workload]
+    kinds = ELEMENT_KINDS[tag]
+    E, M = len(kinds), G * G
+    costs = [parallel.model_costs(k, N, M) for k in kinds]
+    plan = parallel.plan_elements(costs, world, M)
+    if args.plan != "auto" and world > 1:
+        forced = {"elements": None, "grid": [[1] * world] * E, "hybrid": None}
+        if args.plan == "grid":
+            plan = parallel.Plan("grid", forced["grid"], costs, M)
+        elif args.plan == "hybrid":
+            plan = parallel.Plan("hybrid", [parallel._quantise(f, parallel.DEAL_CYCLE) for f in parallel._hybrid_fractions(costs, world)], costs, M)
+        else:
+            w = [[0] * world for _ in range(E)]
+            load = [0.0] * world
+            for e in sorted(range(E), key=lambda e: -sum(costs[e])):
+                r = min(range(world), key=lambda r: load[r])
+                load[r] += sum(costs[e])
+                w[e][r] = 1
+            plan = parallel.Plan("elements", w, costs, M)
+    stream = torch.cuda.current_stream()
+    api = pkg.open_api(dev, stream=stream.cuda_stream)
+    api.enable_timing(True)
+    dp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))
+    data = []
+    grid = None
+    for e, kind in enumerate(kinds):
+        X, y, grid, theta = synthetic(N, G, 20240607 + 3 + e, kind)
+        cplx = kind == "complex"
+        data.append({"cplx": cplx, "X": torch.from_numpy(X).cuda(), "y": torch.from_numpy(np.ascontiguousarray(y).view(np.float64) if cplx else y).cuda(),
+                     "theta": np.ascontiguousarray(theta), "out": torch.empty(5 if cplx else 3, M, dtype=torch.float64, device="cuda"),
+                     "sc": c.ComplexFitScalars() if cplx else c.RealFitScalars()})
+    dgrid = torch.from_numpy(grid).cuda()
+    capi = args.via == "capi"
+    comm, rccl_path = (make_rccl_comm(torch, dist, rank, world) if (capi and (world > 1 or args.comm_at_one)) else (None, None))
+    flags = c.CALC_ERROR | c.CALC_AVERAGE | c.IO_DEVICE
+    predict_flag = 0 if args.prune else c.PREDICT_FULL
+
+    def fit(e):
+        d, h = data[e], C.c_void_p()
+        thp = d["theta"].ctypes.data_as(C.POINTER(C.c_double))
+        if d["cplx"]:
+            st = api.lib.gple_complex_fit_create(api.ctx, thp, dp(d["X"]), dp(d["y"]), N, flags, None, C.byref(h))
+        else:
+            st = api.lib.gple_real_fit_create(api.ctx, thp, dp(d["X"]), dp(d["y"]), 0, N, flags, None, C.byref(h))
+        if st != 0:
+            raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
+        return h
+
+    def predict_dealt(e, h, weights):
+        d = data[e]
+        out = d["out"]
+        o_mean, o_var, o_cut = (out[0:2], out[2], out[3:5]) if d["cplx"] else (out[0], out[1], out[2])
+        if capi or world == 1:
+            fn = api.lib.gple_complex_predict_dealt if d["cplx"] else api.lib.gple_real_predict_dealt
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p] + [C.POINTER(C.c_double)] * 3
+            st = fn(api.ctx, h, dp(dgrid), M, c.IO_DEVICE | predict_flag, rank, world, (C.c_int * world)(*weights), comm, dp(o_mean), dp(o_var), dp(o_cut))
+            if st != 0:
+                raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
+            return out
+        # --via torch: this rank's share by the plain predict, gathered by torch.distributed (complex results travel de-interleaved: rows
+        # Re mean, Im mean, variance, Re cut, Im cut)
+        idx, per = parallel.dealt_indices(M, rank, weights)
+        n, ow = len(idx), 2 if d["cplx"] else 1
+        local = torch.zeros(out.shape[0], per, dtype=torch.float64, device="cuda")
+        if h is not None and n:
+            pts = dgrid[idx.cuda()].contiguous()
+            t_mean, t_var, t_cut = (torch.empty(n * ow, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda"),
+                                    torch.empty(n * ow, dtype=torch.float64, device="cuda"))
+            fn = api.lib.gple_complex_predict if d["cplx"] else api.lib.gple_real_predict
+            ps = c.PredictScalars()
+            st = fn(api.ctx, h, dp(pts), n, c.IO_DEVICE | predict_flag, None, dp(t_mean), dp(t_var), dp(t_cut), C.byref(ps))
+            if st != 0:
+                raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
+            local[0:ow, :n] = t_mean.view(n, ow).t()
+            local[ow, :n] = t_var
+            local[ow + 1:, :n] = t_cut.view(n, ow).t()
+        full = parallel.gather_dealt(local, M, weights, via_host=args.backend == "gloo")
+        out[0:ow].view(-1).view(M, ow).copy_(full[0:ow].t())
+        out[ow].copy_(full[ow])
+        out[ow + 1:].view(-1).view(M, ow).copy_(full[ow + 1:].t())
+        return out
+
+    hybrid = parallel.HybridStep(plan, rank)
+    last = {}
+
+    def step():
+        handles, outs = hybrid.run(fit, predict_dealt)
+        last["outs"] = outs
+        vals = {}
+        for e, h in enumerate(handles):
+            if h is None:
+                continue
+            d = data[e]
+            st = (api.lib.gple_complex_fit_get_scalars if d["cplx"] else api.lib.gple_real_fit_get_scalars)(h, C.byref(d["sc"]))
+            if st != 0 or not np.isfinite(d["sc"].purity):
+                raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode() or "non-finite fit scalars")
+            (api.lib.gple_complex_fit_release if d["cplx"] else api.lib.gple_real_fit_release)(h)
+            if plan.owner(e) == rank:
+                vals[e] = [d["sc"].error, d["sc"].purity]
+        # the elements' scalars (error, purity: what the constraints and ave.txt consume) on every rank
+        last["scalars"] = parallel.allgather_element_scalars(vals, E, 2)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    api.enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.control == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for e, o in enumerate(last["outs"]):
+        if tuple(o.shape) != (5 if data[e]["cplx"] else 3, M) or not bool(torch.isfinite(o).all()):
+            raise RuntimeError(f"element {e}: gathered prediction has the wrong shape or contains non-finite values")
+    if not bool(torch.isfinite(last["scalars"]).all()):
+        raise RuntimeError("non-finite element scalars")
+    ms = 1e3 * elapsed / args.steps
+    _, fit_total, fit_cnt = api.timing(0)
+    _, pk_total, pk_cnt = api.timing(2)
+    # contraction flops this rank executed per step: its share of every element (complex: 2 typed rows per point against the 2N x 2N factor)
+    flops_rank = 0.0
+    for e, kind in enumerate(kinds):
+        pts, _ = parallel.deal_shares(M, plan.weights[e])
+        n, rows = (2 * N, 2 * pts[rank]) if kind == "complex" else (N, pts[rank])
+        flops_rank += float(rows) * n * (n + 1)
+    achieved = flops_rank * args.steps / (pk_total * 1e-3) / 1e12 if pk_total > 0 else 0.0
+    F_step = sum((float(2 * M) * (2 * N) * (2 * N + 1) + float(2 * N) ** 3) if k == "complex" else (float(M) * N * (N + 1) + float(N) ** 3) for k in kinds)
+    result = {
+        "metric": "GP fit+predict ms/step (N samples, M grid pts)", "value": round(ms, 4), "unit": "ms/step", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: all {E} elements of a {'2' if E == 3 else '3'}-state density matrix ({kinds.count('real')} real + {kinds.count('complex')} complex GPs), "
+                               f"N={N} samples each, {G}x{G} grid (M={M}), fit(error+average) + grid predict(mean,var,cutoff) per element"
+                               + (" [--prune: far rows not contracted]" if args.prune else ""),
+                   "N": N, "M": M, "elements": kinds, "parallelism": "single GPU, elements in turn" if world == 1 else f"{world} ranks, plan '{plan.name}'",
+                   "via": args.via, "collective": (f"gple_*_predict_dealt: ncclAllGather inside the library ({rccl_path}), weighted block deal" if comm is not None
+                                                   else ("none (one rank)" if world == 1 else "torch.distributed all_gather_into_tensor")),
+                   "plan": plan.describe()},
+        "roofline": {"bound": "mfma", "kernel": "rownorm2_kernel<4,4,false> (fp64 MFMA triangular contraction ||T k*||^2), all elements of this rank",
+                     "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel_ms": round(pk_total / max(1, pk_cnt), 4), "launches_per_step": pk_cnt / max(1, args.steps),
+                     "algorithmic_flops_per_step_this_rank": flops_rank},
+        "phases_ms": {"fit_device_each": round(fit_total / max(1, fit_cnt), 4), "fits_per_step_this_rank": fit_cnt / max(1, args.steps),
+                      "rownorm_kernel_per_step": round(pk_total / max(1, args.steps), 4)},
+        "mfma_frac_step": round(F_step / (ms * 1e-3) / (FP64_PEAK_TFLOPS * 1e12) / world, 4),
+        "element_scalars": {"error": [float(x) for x in last["scalars"][:, 0]], "purity": [float(x) for x in last["scalars"][:, 1]]},
+    }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if comm is not None:
+        destroy_rccl_comm(comm)
     api.close()
     if world > 1:
         dist.destroy_process_group()
@@ -392,7 +653,7 @@ def step_loop(args, pkg, torch, dist, rank, world, dev):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.control == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not np.isfinite(pop):
@@ -462,7 +723,7 @@ def opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.control == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not bool(torch.isfinite(allv).all()):

@@ -171,7 +171,7 @@ def _cplx(y):
 # every symbol include/gple.h declares (checked by tests/test_capi_symbols.py)
 GPLE_SYMBOLS = [
     "ctx_create", "ctx_destroy", "ctx_synchronize", "ctx_trim", "status_string", "ctx_last_error", "ctx_enable_timing", "ctx_get_timing", "ctx_get_prune_stats",
-    "real_gram", "complex_gram", "cutoff_factor", "predict_batch", "shard_bounds", "set_allgather_function", "real_predict_sharded", "complex_predict_sharded",
+    "real_gram", "complex_gram", "cutoff_factor", "predict_batch", "shard_bounds", "set_allgather_function", "real_predict_sharded", "complex_predict_sharded", "real_predict_dealt", "complex_predict_dealt", "deal_share",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
     "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "minimize_neldermead", "objective_minimize_neldermead", "minimize_auglag_eq", "pes_adiabatic", "evolve", "markov_chain", "markov_chain_trace", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",

@@ -1607,25 +1607,65 @@ extern "C"
 			}();
 			return fn;
 		}
-		// Block-cyclic deal of the test points: 128-point block b belongs to rank b % world (local block b / world).  Contiguous
-		// slices would balance the full contraction just as well, but with far-row pruning (the default) the live blocks of a
-		// phase-space grid sit in one corner of it and a contiguous slice holds anything between all and none of them.
+		// Block-cyclic deal of the test points.  Contiguous slices would balance the full contraction just as well, but with far-row
+		// pruning (the default) the live blocks of a phase-space grid sit in one corner of it and a contiguous slice holds anything
+		// between all and none of them.  Plain deal: 128-point block b belongs to rank b % world (local block b / world).  Weighted deal
+		// (plans that give the ranks unequal shares of an element): out of every cycle of S = sum(w) consecutive blocks rank
+		// r takes the w[r] blocks cum[r] .. cum[r] + w[r] - 1; the plain deal is w = 1 for everyone.
 		constexpr size_t SHARD_BLOCK = 128;
-		__global__ void __launch_bounds__(256) shard_points_kernel(const double* __restrict__ Xs, size_t M, int rank, int world, size_t n_local,
+		constexpr int DEAL_MAX_WORLD = 64;
+		struct Deal
+		{
+			int world, S;
+			int cum[DEAL_MAX_WORLD + 1];
+			__host__ __device__ int weight(int r) const { return cum[r + 1] - cum[r]; }
+			__host__ __device__ int owner(size_t b) const
+			{
+				const int p = static_cast<int>(b % S);
+				int r = 0;
+				while (cum[r + 1] <= p) ++r;
+				return r;
+			}
+			// block `lb` of rank r's share -> block of the grid
+			__host__ __device__ size_t global_block(int r, size_t lb) const { return (lb / weight(r)) * S + cum[r] + lb % weight(r); }
+			// block b of the grid (owned by r) -> block of r's share
+			__host__ __device__ size_t local_block(int r, size_t b) const { return (b / S) * weight(r) + (b % S - cum[r]); }
+			size_t blocks_of(int r, size_t nblocks) const
+			{
+				const size_t rem = nblocks % S, w = static_cast<size_t>(weight(r)), c = static_cast<size_t>(cum[r]);
+				return (nblocks / S) * w + (rem > c ? std::min(rem - c, w) : 0);
+			}
+		};
+		bool make_deal(int world, const int* weights, Deal& d)
+		{
+			if (world < 1 || world > DEAL_MAX_WORLD) return false;
+			d.world = world, d.cum[0] = 0;
+			for (int r = 0; r < world; ++r)
+			{
+				const int w = weights ? weights[r] : 1;
+				if (w < 0 || w > (1 << 20)) return false;
+				d.cum[r + 1] = d.cum[r] + w;
+			}
+			d.S = d.cum[world];
+			return d.S > 0;
+		}
+		__global__ void __launch_bounds__(256) shard_points_kernel(const double* __restrict__ Xs, size_t M, int rank, Deal deal, size_t n_local,
 			double* __restrict__ out)
 		{
 			const size_t j = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
 			if (j >= n_local) return;
-			const size_t i = ((j / SHARD_BLOCK) * world + rank) * SHARD_BLOCK + j % SHARD_BLOCK;
+			const size_t i = deal.global_block(rank, j / SHARD_BLOCK) * SHARD_BLOCK + j % SHARD_BLOCK;
 			out[2 * j] = Xs[2 * i], out[2 * j + 1] = Xs[2 * i + 1];
 		}
 		// gathered[r][...] (world blocks of (2 ow + 1) * per doubles: mean | var | cut of rank r's points) -> full-length outputs
-		__global__ void __launch_bounds__(256) unshard_kernel(const double* __restrict__ g, size_t per, int ow, size_t M, int world, double* __restrict__ mean,
+		__global__ void __launch_bounds__(256) unshard_kernel(const double* __restrict__ g, size_t per, int ow, size_t M, Deal deal, double* __restrict__ mean,
 			double* __restrict__ var, double* __restrict__ cut)
 		{
 			const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
 			if (i >= M) return;
-			const size_t b = i / SHARD_BLOCK, r = b % world, q = (b / world) * SHARD_BLOCK + i % SHARD_BLOCK;
+			const size_t b = i / SHARD_BLOCK;
+			const int r = deal.owner(b);
+			const size_t q = deal.local_block(r, b) * SHARD_BLOCK + i % SHARD_BLOCK;
 			const double* __restrict__ blk = g + r * (2 * ow + 1) * per;
 			for (int k = 0; k < ow; ++k)
 			{
@@ -1634,17 +1674,30 @@ extern "C"
 			}
 			if (var) var[i] = blk[ow * per + q];
 		}
+		// rank's share under a deal: its number of points and the padded share length every rank allocates
+		void deal_counts(const Deal& d, size_t M, int rank, size_t& n_local, size_t& per)
+		{
+			const size_t nblocks = (M + SHARD_BLOCK - 1) / SHARD_BLOCK;
+			size_t most = 0;
+			for (int r = 0; r < d.world; ++r) most = std::max(most, d.blocks_of(r, nblocks));
+			per = most * SHARD_BLOCK;
+			n_local = d.blocks_of(rank, nblocks) * SHARD_BLOCK;
+			if (nblocks && d.owner(nblocks - 1) == rank) n_local -= nblocks * SHARD_BLOCK - M; // owner of the short block: it is the last of its share
+		}
 	} // namespace
 	int gple_set_allgather_function(void* fn)
 	{
 		allgather_override.store(reinterpret_cast<allgather_fn>(fn));
 		return GPLE_OK;
 	}
-	static int predict_sharded(gple_ctx* ctx, const FitCommon* f, const double* Xs, size_t M, unsigned flags, int rank, int world, void* comm,
-		double* prediction, double* variance, double* cutoff_prediction)
+	static int predict_sharded(gple_ctx* ctx, const FitCommon* f, bool is_complex, const double* Xs, size_t M, unsigned flags, int rank, int world, const int* weights,
+		void* comm, double* prediction, double* variance, double* cutoff_prediction)
 	{
 		if (world < 1 || rank < 0 || rank >= world) return GPLE_ERR_BAD_ARG;
 		if (world > 1 && !comm) return GPLE_ERR_BAD_ARG;
+		Deal deal;
+		if (!make_deal(world, weights, deal)) return GPLE_ERR_BAD_ARG;
+		if (!f && deal.weight(rank) > 0) return GPLE_ERR_BAD_ARG; // only a rank without a share may come without the fit
 		if (M == 0) return GPLE_OK;
 		const bool dev = flags & GPLE_IO_DEVICE;
 		if (!comm) return predict_common(ctx, f, Xs, M, flags & (GPLE_IO_DEVICE | GPLE_PREDICT_FULL), nullptr, prediction, variance, cutoff_prediction, nullptr);
@@ -1656,12 +1709,10 @@ extern "C"
 			ctx->last_error = std::string("ncclAllGather not found: ") + (de ? de : "librccl is not loadable");
 			return GPLE_ERR_COLLECTIVE;
 		}
-		// this rank's points: the 128-point blocks rank, rank + world, ... (the last block of the set may be short)
-		const size_t nblocks = (M + SHARD_BLOCK - 1) / SHARD_BLOCK, per = (nblocks + world - 1) / world * SHARD_BLOCK;
-		const size_t my_blocks = nblocks > static_cast<size_t>(rank) ? (nblocks - rank + world - 1) / world : 0;
-		size_t n_local = my_blocks * SHARD_BLOCK;
-		if (my_blocks && ((my_blocks - 1) * world + rank) == nblocks - 1) n_local -= nblocks * SHARD_BLOCK - M; // owner of the short block
-		const size_t ow = f->is_complex ? 2 : 1, blk = (2 * ow + 1) * per;
+		// this rank's points: its blocks of every cycle (the last block of the grid may be short)
+		size_t n_local = 0, per = 0;
+		deal_counts(deal, M, rank, n_local, per);
+		const size_t ow = is_complex ? 2 : 1, blk = (2 * ow + 1) * per;
 		hipStream_t st = ctx->stream;
 		// the points go through device buffers whatever the caller's pointers are: the collective runs on device memory
 		Scratch local(ctx), gathered(ctx), xs_all(ctx), xs(ctx), om(ctx), ov(ctx), oc(ctx);
@@ -1681,7 +1732,7 @@ extern "C"
 			if (n_local)
 			{
 				GPLE_HIP(ctx, xs.get(2 * n_local));
-				hipLaunchKernelGGL(shard_points_kernel, dim3(static_cast<unsigned>((n_local + 255) / 256)), dim3(256), 0, st, all_dev, M, rank, world, n_local, xs.p);
+				hipLaunchKernelGGL(shard_points_kernel, dim3(static_cast<unsigned>((n_local + 255) / 256)), dim3(256), 0, st, all_dev, M, rank, deal, n_local, xs.p);
 				GPLE_HIP(ctx, hipGetLastError());
 			}
 		}
@@ -1735,7 +1786,7 @@ extern "C"
 				d_cut = oc.p;
 			}
 		}
-		hipLaunchKernelGGL(unshard_kernel, dim3(static_cast<unsigned>((M + 255) / 256)), dim3(256), 0, st, gathered.p, per, static_cast<int>(ow), M, world, d_mean, d_var,
+		hipLaunchKernelGGL(unshard_kernel, dim3(static_cast<unsigned>((M + 255) / 256)), dim3(256), 0, st, gathered.p, per, static_cast<int>(ow), M, deal, d_mean, d_var,
 			d_cut);
 		GPLE_HIP(ctx, hipGetLastError());
 		if (!dev)
@@ -1753,14 +1804,40 @@ extern "C"
 	{
 		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
-		return predict_sharded(ctx, fit, Xs, M, flags, rank, world, nccl_comm, prediction, variance, cutoff_prediction);
+		return predict_sharded(ctx, fit, false, Xs, M, flags, rank, world, nullptr, nccl_comm, prediction, variance, cutoff_prediction);
 	}
 	int gple_complex_predict_sharded(gple_ctx* ctx, const gple_complex_fit* fit, const double* Xs, size_t M, unsigned flags, int rank, int world,
 		void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction)
 	{
 		if (!ctx || !fit || (M && !Xs)) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
-		return predict_sharded(ctx, fit, Xs, M, flags, rank, world, nccl_comm, prediction, variance, cutoff_prediction);
+		return predict_sharded(ctx, fit, true, Xs, M, flags, rank, world, nullptr, nccl_comm, prediction, variance, cutoff_prediction);
+	}
+	int gple_real_predict_dealt(gple_ctx* ctx, const gple_real_fit* fit, const double* Xs, size_t M, unsigned flags, int rank, int world,
+		const int* weights, void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction)
+	{
+		if (!ctx || (M && !Xs)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		return predict_sharded(ctx, fit, false, Xs, M, flags, rank, world, weights, nccl_comm, prediction, variance, cutoff_prediction);
+	}
+	int gple_complex_predict_dealt(gple_ctx* ctx, const gple_complex_fit* fit, const double* Xs, size_t M, unsigned flags, int rank, int world,
+		const int* weights, void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction)
+	{
+		if (!ctx || (M && !Xs)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		return predict_sharded(ctx, fit, true, Xs, M, flags, rank, world, weights, nccl_comm, prediction, variance, cutoff_prediction);
+	}
+	int gple_deal_share(size_t M, int rank, int world, const int* weights, size_t* n_local, size_t* per, size_t* indices)
+	{
+		Deal deal;
+		if (rank < 0 || rank >= world || !make_deal(world, weights, deal)) return GPLE_ERR_BAD_ARG;
+		size_t nl = 0, p = 0;
+		deal_counts(deal, M, rank, nl, p);
+		if (n_local) *n_local = nl;
+		if (per) *per = p;
+		if (indices)
+			for (size_t j = 0; j < nl; ++j) indices[j] = deal.global_block(rank, j / SHARD_BLOCK) * SHARD_BLOCK + j % SHARD_BLOCK;
+		return GPLE_OK;
 	}
 
 	// ---- batched point-predict (N1): gather -> one predict per element -> scatter ------------------------------------

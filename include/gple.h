@@ -241,6 +241,18 @@ int gple_real_predict_sharded(gple_ctx* ctx, const gple_real_fit* fit, const dou
 	void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction);
 int gple_complex_predict_sharded(gple_ctx* ctx, const gple_complex_fit* fit, const double* Xs, size_t M, unsigned flags, int rank,
 	int world, void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction);
+/* Weighted deal, for plans that give the ranks unequal shares of an element's grid (the elements of TrainingKernels,
+ * predict.cpp:290-360, differ 8x in cost, and 3 + 3 elements do not divide 8 GPUs): out of every cycle of S = sum(weights) consecutive
+ * 128-point blocks rank r predicts the weights[r] blocks that follow those of the ranks before it.  weights[rank] == 0: the rank takes no
+ * part in this element (fit may be NULL) but still enters the all-gather — every rank of the communicator calls this once per element, in
+ * the same order — and receives the full result like everyone else.  weights == NULL is the plain deal of gple_*_predict_sharded. */
+int gple_real_predict_dealt(gple_ctx* ctx, const gple_real_fit* fit, const double* Xs, size_t M, unsigned flags, int rank, int world,
+	const int* weights, void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction);
+int gple_complex_predict_dealt(gple_ctx* ctx, const gple_complex_fit* fit, const double* Xs, size_t M, unsigned flags, int rank, int world,
+	const int* weights, void* nccl_comm, double* prediction, double* variance, double* cutoff_prediction);
+/* Host-only view of a deal (no device call): the number of points of rank's share, the padded share length every rank allocates, and
+ * (indices != NULL, n_local entries) the grid indices of the share in the order the rank predicts them. */
+int gple_deal_share(size_t M, int rank, int world, const int* weights, size_t* n_local, size_t* per, size_t* indices);
 
 /* ---- batched point-predict ------------------------------------------------------------------ */
 /* The reference evaluates its DistributionFunction (stdafx.h:155) one phase-space point at a time: main.cpp:75-101 constructs a

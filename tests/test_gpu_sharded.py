@@ -150,3 +150,71 @@ print("STATUS", st, msg.decode())
     line = [l for l in res.stdout.splitlines() if l.startswith("STATUS")][0].split(" ", 2)
     assert int(line[1]) == 5, res.stdout  # GPLE_ERR_COLLECTIVE (include/gple.h)
     assert "ncclAllGather not found" in line[2] and len(line[2]) > len("ncclAllGather not found: ")
+
+
+@pytest.mark.parametrize("weights,cplx", [([3, 0, 5], False), ([2, 1], True), ([0, 1], False)])
+def test_weighted_deal_between_threads(gpu, weights, cplx):
+    """gple_*_predict_dealt (the hybrid element x grid plans of DESIGN.md §7): unequal shares, a rank without a share comes without the fit and
+    still gets the full grid; every rank's result equals the shares predicted unsharded, bit for bit."""
+    so = os.path.join(ROOT, "tests", "cpp", "libfake_allgather.so")
+    if not os.path.exists(so):
+        pytest.fail("tests/cpp/libfake_allgather.so missing: run __graft_entry__.build()")
+    import gaussian_process_liouville_equation_amd as pkg
+    world = len(weights)
+    fake = C.CDLL(so)
+    fake.fake_group_create.restype = C.c_void_p
+    fake.fake_comm_create.restype = C.c_void_p
+    fake.fake_comm_create.argtypes = [C.c_void_p, C.c_int]
+    fake.fake_comm_destroy.argtypes = [C.c_void_p]
+    fake.fake_group_destroy.argtypes = [C.c_void_p]
+    gpu.lib.gple_set_allgather_function.argtypes = [C.c_void_p]
+    gpu.lib.gple_set_allgather_function(C.cast(fake.fake_allgather, C.c_void_p))
+    try:
+        M = 2000  # 16 blocks, the last one short
+        X, yr, Xs = parity.synthetic_real(150, M, 19)
+        y = 0.5 * yr * np.exp(0.5j * (X[:, 0] + 10.0)) if cplx else yr
+        theta = [1.0, 1.1, 0.8, 0.7, 0.9, 0.7, 0.8, 0.05] if cplx else [1.0, 0.7086, 0.7056, 1e-2]
+        fit0 = (gpu.complex_fit if cplx else gpu.real_fit)(theta, X, y, 0)
+        pred = gpu.complex_predict if cplx else gpu.real_predict
+        ref = {"prediction": np.empty(M, dtype=complex if cplx else float), "variance": np.empty(M), "cutoff": np.empty(M, dtype=complex if cplx else float)}
+        for r in range(world):
+            idx = parallel.dealt_indices(M, r, weights)[0].numpy()
+            if len(idx):
+                part = pred(fit0, Xs[idx])
+                for k in ref:
+                    ref[k][idx] = part[k]
+        group = fake.fake_group_create(world)
+        out, errs = {}, []
+        ow = 2 if cplx else 1
+
+        def rank_main(r):
+            try:
+                api = pkg.open_api(0)
+                fit = (api.complex_fit if cplx else api.real_fit)(theta, X, y, 0) if weights[r] else None
+                comm = fake.fake_comm_create(group, r)
+                mean, var, cut = np.empty(ow * M), np.empty(M), np.empty(ow * M)
+                fn = api.lib.gple_complex_predict_dealt if cplx else api.lib.gple_real_predict_dealt
+                fn.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, _dp, _dp, _dp]
+                st = fn(api.ctx, fit.handle if fit else None, np.ascontiguousarray(Xs).ctypes.data_as(_dp), M, 0, r, world, (C.c_int * world)(*weights), comm,
+                        mean.ctypes.data_as(_dp), var.ctypes.data_as(_dp), cut.ctypes.data_as(_dp))
+                assert st == 0, (st, api.lib.gple_ctx_last_error(api.ctx))
+                out[r] = (mean.view(np.complex128), var, cut.view(np.complex128)) if cplx else (mean, var, cut)
+                fake.fake_comm_destroy(comm)
+                api.close()
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join(timeout=120) for t in th]
+        assert not errs, errs
+        fake.fake_group_destroy(group)
+        for r in range(world):
+            mean, var, cut = out[r]
+            assert np.array_equal(mean, ref["prediction"]) and np.array_equal(var, ref["variance"]) and np.array_equal(cut, ref["cutoff"])
+        # a rank with a share but without the fit is a caller error, not a hang
+        fn = gpu.lib.gple_real_predict_dealt
+        fn.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, _dp, _dp, _dp]
+        assert fn(gpu.ctx, None, np.ascontiguousarray(Xs).ctypes.data_as(_dp), M, 0, 0, 2, (C.c_int * 2)(1, 1), C.c_void_p(1), None, None, None) == 1
+    finally:
+        gpu.lib.gple_set_allgather_function(None)
