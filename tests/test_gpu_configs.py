@@ -250,6 +250,48 @@ def test_c5_real_element_full_grid(gpu):
     assert np.abs((kss - np.einsum("ij,jk,ik->i", Ks, W, Ks)) - p["variance"][rows]).max() <= 3e-7
 
 
+def test_c5_complex_element_full_grid(gpu):
+    """configs[4]: an off-diagonal element at N = 8192 (n = 16384 in the [Re; Im] embedding) on the 1024 x 1024 grid, every row contracted and
+    with the library's default pruning: augmented-system residuals on probe vectors, the reference's 4-term variance form
+    (complex_kernel.cpp:608-642) on 32 rows by numpy, variance range, far field, and pruned == full bit for bit"""
+    N, G = 8192, 1024
+    X, y, grid, _ = config_inputs(N, G, 20240607 + 4, cplx=True)
+    fit = gpu.complex_fit(THETA_C, X, y, 3)
+    assert fit.scalars["info"] == 0 and np.isfinite(fit.scalars["error"]) and np.isfinite(fit.scalars["purity"])
+    gpu.prune_stats(reset=True)
+    p = gpu.complex_predict(fit, grid)
+    live, seen = gpu.prune_stats(reset=True)
+    assert seen == 2 * G * G // 128 and 0 < live < 0.25 * seen, (live, seen)  # the packet occupies a corner of the phase-space box
+    assert len(p["variance"]) == G * G
+    full = gpu.complex_predict(fit, grid, flags=c.PREDICT_FULL)
+    for k in ("prediction", "variance", "cutoff"):
+        assert np.array_equal(full[k], p[k]), k
+    del full
+    rows = np.argsort(((grid - [X0, P0]) ** 2).sum(axis=1))[:32]
+    kss = check_complex_fit_and_rows(gpu, fit, THETA_C, X, grid, p, rows)
+    assert p["variance"].min() >= -1e-7 and p["variance"].max() <= kss + 1e-12
+    far = np.abs(grid[:, 0] + 10) > 8
+    assert np.abs(p["prediction"][far]).max() <= 1e-9 and np.abs(p["variance"][far] - kss).max() <= 1e-9
+    assert np.all(np.abs(p["cutoff"]) <= np.abs(p["prediction"]) / fit.scalars["rescale_factor"] + 1e-15)
+    fit.release()
+
+
+@pytest.mark.parametrize("N,G,cplx", [(8192, 1024, False), (4096, 512, True)])
+def test_pruned_equals_full_at_config_size(gpu, N, G, cplx):
+    """C5r and C4c: the library's default predict (far rows not contracted) against GPLE_PREDICT_FULL, bit for bit, at the sizes bench.py reports"""
+    X, y, grid, _ = config_inputs(N, G, 20240607 + 5, cplx=cplx)
+    fit = (gpu.complex_fit if cplx else gpu.real_fit)(THETA_C if cplx else THETA_R, X, y, 0)
+    pred = gpu.complex_predict if cplx else gpu.real_predict
+    gpu.prune_stats(reset=True)
+    a = pred(fit, grid)
+    live, seen = gpu.prune_stats(reset=True)
+    assert seen == (2 if cplx else 1) * G * G // 128 and 0 < live < 0.25 * seen, (live, seen)
+    b = pred(fit, grid, flags=c.PREDICT_FULL)
+    for k in ("prediction", "variance", "cutoff"):
+        assert np.array_equal(a[k], b[k]), k
+    fit.release()
+
+
 def test_c5_three_state_elements_against_oracle(gpu, oracle):
     """NumPES = 3 (stdafx.h:111 recompiled): 3 real + 3 complex elements; the GP code is generic in NumPES.
     Sizes the oracle finishes in seconds; aggregates and their gradient packing HIP vs oracle."""

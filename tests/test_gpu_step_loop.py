@@ -266,3 +266,42 @@ def test_main_tick_rules(gpu):
     d2, x2, s2, k2, res2 = S.main_tick(2, d1, x1, s1, mc, opt, k1, MASS, DT, 2, 160, 1.0, rng, S.DAC, gpu)
     assert res2 is not None and len(x2[(0, 0)][0]) == 160 and not np.array_equal(x2[(0, 0)][0], x1[(0, 0)][0])
     assert abs(k2.calculate_population() - 1.0) < 0.1
+
+
+def test_tick_at_c5_size(gpu):
+    """configs[4]: one tick of main.cpp:143-176 at N = 8192 points per element (evolve the density and 5N extra points per element — 48 N
+    back-propagated predicts per element in one batch each — then refit).  Population and purity of the refitted kernels stay within the drift
+    the reference tolerates before it re-optimises (main.cpp:179-188: 10 %), coordinates move by the classical step, and the batched tick equals
+    the same tick on 8 spot-checked points alone (the few-points predict path) to the accuracy two GP predicts allow."""
+    from gaussian_process_liouville_equation_amd import steploop
+    N = 8192
+    rng = np.random.Generator(np.random.PCG64(20240607 + 8))
+    dens, extra = {}, {}
+    xc = -1.5
+    for e, (i, j) in enumerate(K.element_order(2)):
+        for store, n in ((dens, N), (extra, 5 * N)):
+            r = rng.normal([xc, 14.112], [0.7086, 0.7056], size=(n, 2))
+            g = np.exp(-0.5 * (((r[:, 0] - xc) / 0.7086) ** 2 + ((r[:, 1] - 14.112) / 0.7056) ** 2)) / (2 * np.pi * 0.7086 * 0.7056)
+            store[(i, j)] = (r, (g * (0.6, 0.3 * np.exp(0.4j * (r[:, 0] - xc)), 0.4)[e]).astype(complex))
+    thc = [1.0, 1.0, 0.7086, 0.7056, 1.0, 0.7086, 0.7056, 1e-2]
+    params = {(0, 0): TH, (1, 0): thc, (1, 1): TH}
+    k0 = K.TrainingKernels(params, K.construct_training_sets(dens), True, True, False, api=gpu)
+    pop0, pur0 = k0.calculate_population(), k0.calculate_purity()
+    assert abs(pop0 - 1.0) <= 0.02
+    d1, x1, k1 = steploop.tick(dens, extra, params, MASS, DT, k0, steploop.DAC)
+    for e in dens:
+        assert d1[e][0].shape == dens[e][0].shape and x1[e][0].shape == extra[e][0].shape
+        assert np.all(np.isfinite(d1[e][1])) and np.all(np.isfinite(x1[e][1]))
+        # one classical step: dx = p dt / m up to the force's second-order term
+        assert np.abs(d1[e][0][:, 0] - dens[e][0][:, 0] - dens[e][0][:, 1] * DT / MASS).max() <= 1e-3
+    pop1, pur1 = k1.calculate_population(), k1.calculate_purity()
+    assert abs(pop1 - pop0) <= 0.05 * abs(pop0), (pop0, pop1)
+    assert abs(pur1 - pur0) <= 0.10 * abs(pur0), (pur0, pur1)
+    # spot check: the same tick for 8 points per element alone
+    idx = rng.choice(N, 8, replace=False)
+    sub = {e: (dens[e][0][idx], dens[e][1][idx]) for e in dens}
+    s1 = steploop.evolve(sub, MASS, DT, k0, steploop.DAC)
+    for e in dens:
+        assert np.array_equal(s1[e][0], d1[e][0][idx])
+        scale = np.abs(dens[e][1]).max()
+        assert np.abs(s1[e][1] - d1[e][1][idx]).max() <= 1e-8 * scale, e
