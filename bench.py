@@ -188,7 +188,25 @@ def destroy_rccl_comm(comm):
         rccl.ncclCommDestroy(comm)
 
 
+def _keep_stdout_for_the_json_line():
+    """RCCL prints a version banner on STDOUT when a communicator is created; the driver parses stdout as ONE JSON line.  File descriptor 1
+    is pointed at stderr for the life of the process and the result line goes to a duplicate of the original stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
+def emit(result):
+    OUT.write(json.dumps(result) + "\n")
+    OUT.flush()
+
+
+OUT = sys.stdout
+
+
 def main():
+    global OUT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -212,6 +230,7 @@ def main():
                          "ranks and all-gathered; 'elements' = weak scaling over the independent density-matrix elements, every "
                          "rank fits and predicts its own element on the whole grid, no data-path collective (SURVEY.md §8e)")
     args = ap.parse_args()
+    OUT = _keep_stdout_for_the_json_line()
 
     import torch
     import torch.distributed as dist
@@ -227,6 +246,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
     torch.cuda.set_device(dev)
+    # Everything (the library's kernels, torch's copies, the collectives) runs on ONE non-blocking stream, not on the legacy null stream:
+    # once another library has created blocking streams in the process (RCCL does), every launch on the null stream pays for the implicit
+    # synchronisation with them — the fit's 64 dependent panel launches took 3.9 ms instead of 2.0 ms with a communicator in the process
+    # (gpurun_out/r03_bench_c4r_capi1.json of round 3; probes/rccl_fit_interference.py shows a context with its own stream is unaffected)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     multi = WORKLOADS[args.workload][2] in ELEMENT_KINDS
     grid_wl = WORKLOADS[args.workload][2] in ("real", "complex")
     if args.via is None:
@@ -255,7 +279,7 @@ def main():
     X, y, grid, theta = synthetic(N, G, 20240607 + 1 + (rank if by_element else 0), kernel)
 
     stream = torch.cuda.current_stream()
-    api = pkg.open_api(dev, stream=stream.cuda_stream)  # the library runs on torch's current stream
+    api = pkg.open_api(dev, stream=None if os.environ.get("BENCH_OWN_STREAM") else stream.cuda_stream)  # the library runs on torch's current stream
     api.enable_timing(True)
     dX = torch.from_numpy(X).cuda()
     dy = torch.from_numpy(np.ascontiguousarray(y).view(np.float64) if cplx else y).cuda()
@@ -275,7 +299,9 @@ def main():
     dgrid_mine = dgrid_all[shard.idx.to(dgrid_all.device)].contiguous() if shard.cyclic else None
     # --via capi: the product's own collective.  One ncclComm_t per process from the librccl of this process; the library resolves
     # ncclAllGather from the process image, i.e. from the same library.
-    capi = args.via == "capi" and not by_element and (world > 1 or args.comm_at_one)
+    capi = args.via == "capi" and not by_element and (world > 1 or args.comm_at_one) and not os.environ.get("BENCH_COMM_UNUSED")
+    if os.environ.get("BENCH_COMM_UNUSED"):
+        make_rccl_comm(torch, dist, rank, world)
     comm, via_note = None, ("torch.distributed all_gather_into_tensor" if world > 1 else "no collective (one rank)")
     if capi:
         comm, rccl_path = make_rccl_comm(torch, dist, rank, world)
@@ -437,7 +463,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(args.workload, N, G, kernel, X, y, grid, theta)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     if comm is not None:
         destroy_rccl_comm(comm)
     api.close()
@@ -607,7 +633,7 @@ def elements_step(args, pkg, c, parallel, torch, dist, rank, world, dev):
         "element_scalars": {"error": [float(x) for x in last["scalars"][:, 0]], "purity": [float(x) for x in last["scalars"][:, 1]]},
     }
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     if comm is not None:
         destroy_rccl_comm(comm)
     api.close()
@@ -675,7 +701,7 @@ def step_loop(args, pkg, torch, dist, rank, world, dev):
         "population_after": pop,
     }
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     api.close()
     if world > 1:
         dist.destroy_process_group()
@@ -758,7 +784,7 @@ def opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev):
         "phases_ms": per_elem,
     }
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     for o in objs.values():
         o.release()
     pool.close()

@@ -2331,6 +2331,15 @@ extern "C"
 		return GPLE_OK;
 	}
 
+	/* gple_debug.h: the outcome of the side stream's queue probing (gple_chol.hip, pick_side_stream) */
+	int gple_debug_side_stream(gple_ctx* ctx, int* attempts, int* overlaps)
+	{
+		if (!ctx || !attempts || !overlaps) return GPLE_ERR_BAD_ARG;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		*attempts = ctx->side_attempts, *overlaps = ctx->side_overlaps ? 1 : 0;
+		return GPLE_OK;
+	}
+
 	/* gple_debug.h: instrumented launches of the one-launch panel step (potrf_step_kernel) at block column 1 of an n x n matrix,
 	 * n = 128 + below (below = 0 | 64), column-major on the host, overwritten with what the first launch leaves; T (n x n) likewise. */
 	int gple_debug_potrf_step(gple_ctx* ctx, double* A, double* T, int pend, int below, long long* stamps, int reps, float* ms_per_launch)

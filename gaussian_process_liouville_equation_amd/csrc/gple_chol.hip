@@ -1076,6 +1076,91 @@ namespace gple
 		const int t = gemm_pick_tile(m, ncols, batch, true);
 		return t == 128 && origin % 128 ? 64 : t;
 	}
+	// The side stream must sit on another hardware queue than the main stream.  HIP binds its streams to a handful of hardware queues
+	// (GPU_MAX_HW_QUEUES, 4 by default) as they are created, by use count: whether the stream created here shares the main stream's queue
+	// depends on how many streams the process made before — torch's, RCCL's — and when it does, the block-row inverse runs after the panels
+	// instead of beside them, or worse: N = 4096 fit 2.0 -> 2.4 ms (default priority) / 3.9 ms (low priority) with an RCCL communicator
+	// created first (probes/hwqueue_fit_probe.py, profiles/r03_notes.md).  So candidates are tried: a short spin kernel on each of the two
+	// streams, started together; on one queue they take twice as long as on two.  Rejected candidates are kept alive until one is accepted
+	// (their queues stay taken, so the next candidate goes elsewhere), then destroyed.  Once per context, ~0.3 ms per candidate.
+	namespace
+	{
+		__global__ void spin_kernel(long long ticks)
+		{
+			const long long t0 = wall_clock64();
+			while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+		}
+	} // namespace
+	static hipError_t pick_side_stream(Ctx* ctx, hipStream_t main_stream)
+	{
+		// the side stream's GEMMs fill whatever the panel launches leave idle and must not be dispatched ahead of them: lowest priority
+		static const int side_prio = [] {
+			const char* ev = getenv("GPLE_CHOL_SIDE_PRIORITY"); // 0: default priority (A/B)
+			int lo = 0, hi = 0;
+			if ((ev && atoi(ev) == 0) || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return 0;
+			return lo;
+		}();
+		static const bool probe = [] {
+			const char* ev = getenv("GPLE_CHOL_SIDE_PROBE"); // 0: take the first stream whatever queue it is on (A/B)
+			return ev == nullptr || atoi(ev) != 0;
+		}();
+		constexpr int MAX_CANDIDATES = 8;
+		constexpr long long SPIN_TICKS = 10000; // 100 us of the 100 MHz wall clock
+		hipError_t e;
+		hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+		for (hipEvent_t& x : ev)
+			if ((e = hipEventCreate(&x)) != hipSuccess) return e;
+		std::vector<hipStream_t> rejected;
+		hipStream_t chosen = nullptr;
+		for (int attempt = 0; attempt < MAX_CANDIDATES && !chosen; ++attempt)
+		{
+			hipStream_t cand = nullptr;
+			if ((e = hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, side_prio)) != hipSuccess) break;
+			ctx->side_attempts = attempt + 1;
+			if (!probe)
+			{
+				chosen = cand;
+				break;
+			}
+			// both spins start at ev[0]; ev[1] / ev[2] close the main / the candidate's one
+			float t_main = 0.f, t_side = 0.f, t_ref = 0.f;
+			bool ok = hipEventRecord(ev[0], main_stream) == hipSuccess && hipStreamWaitEvent(cand, ev[0], 0) == hipSuccess;
+			if (ok)
+			{
+				hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, main_stream, SPIN_TICKS);
+				hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cand, SPIN_TICKS);
+				ok = hipEventRecord(ev[1], main_stream) == hipSuccess && hipEventRecord(ev[2], cand) == hipSuccess && hipStreamSynchronize(cand) == hipSuccess
+					&& hipStreamSynchronize(main_stream) == hipSuccess && hipEventElapsedTime(&t_main, ev[0], ev[1]) == hipSuccess
+					&& hipEventElapsedTime(&t_side, ev[0], ev[2]) == hipSuccess;
+			}
+			// one spin alone, for the scale (launch latency included)
+			if (ok)
+			{
+				ok = hipEventRecord(ev[0], main_stream) == hipSuccess;
+				hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, main_stream, SPIN_TICKS);
+				ok = ok && hipEventRecord(ev[1], main_stream) == hipSuccess && hipStreamSynchronize(main_stream) == hipSuccess
+					&& hipEventElapsedTime(&t_ref, ev[0], ev[1]) == hipSuccess;
+			}
+			if (!ok || std::max(t_main, t_side) < 1.6f * t_ref)
+			{
+				chosen = cand; // (a failed measurement is not a reason to go without a side stream)
+				ctx->side_overlaps = ok;
+			}
+			else rejected.push_back(cand);
+		}
+		if (!chosen && !rejected.empty()) // every candidate shared the main stream's queue: the last one will have to do
+		{
+			chosen = rejected.back();
+			rejected.pop_back();
+		}
+		for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+		for (hipEvent_t x : ev) (void)hipEventDestroy(x);
+		(void)hipGetLastError();
+		if (!chosen) return hipErrorOutOfMemory;
+		ctx->side_stream = chosen;
+		return hipSuccess;
+	}
+
 	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work, double* uvec)
 	{
 		if (n % NB) return hipErrorInvalidValue;
@@ -1090,14 +1175,7 @@ namespace gple
 		hipError_t e;
 		if (!ctx->side_stream)
 		{
-			// the side stream's GEMMs fill whatever the panel launches leave idle and must not be dispatched ahead of them: lowest priority
-			static const int side_prio = [] {
-				const char* ev = getenv("GPLE_CHOL_SIDE_PRIORITY"); // 0: default priority (A/B)
-				int lo = 0, hi = 0;
-				if ((ev && atoi(ev) == 0) || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return 0;
-				return lo;
-			}();
-			if ((e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, side_prio)) != hipSuccess) return e;
+			if ((e = pick_side_stream(ctx, s)) != hipSuccess) return e;
 			if ((e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming)) != hipSuccess) return e;
 		}
 		while (ctx->side_forks.size() < forks.size())

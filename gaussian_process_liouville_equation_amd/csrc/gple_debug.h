@@ -3,7 +3,8 @@
  *   tests/test_gpu_chol_diag.py, probes/diag_probe.py -> gple_debug_potrf_diag
  *   tests/test_gpu_chol_diag.py, probes/step_probe.py -> gple_debug_potrf_step
  *   tests/test_host_logic.py                          -> gple_debug_chol_layout (no device call)
- *   tests/test_gpu_gemm.py                            -> gple_debug_gemm */
+ *   tests/test_gpu_gemm.py                            -> gple_debug_gemm
+ *   tests/test_gpu_chol_diag.py                       -> gple_debug_side_stream */
 #ifndef GPLE_DEBUG_H
 #define GPLE_DEBUG_H
 #include "../../include/gple.h"
@@ -24,6 +25,9 @@ extern "C"
 	 * in gple_internal.h; tile = 32 | 64 | 128 | 0 (the library's own choice). */
 	int gple_debug_gemm(gple_ctx* ctx, const double* A, long lda, int a_kmajor, const double* B, long ldb, int b_kmajor, double* C, long ldc,
 		int c_trans, int M, int N, int K, double alpha, double beta, int krange, int lower_only, int tile);
+	/* The side stream the context's fits run their block-row inverse on (created by the first fit with n >= 1024): how many candidate streams
+	 * were tried until one ran beside the main stream, and whether the chosen one did (0: none did, or no fit has needed one yet). */
+	int gple_debug_side_stream(gple_ctx* ctx, int* attempts, int* overlaps);
 #ifdef __cplusplus
 }
 #endif

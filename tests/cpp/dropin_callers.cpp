@@ -9,9 +9,13 @@
 //   opt.cpp:622-719   diagonal_constraints on TrainingKernels aggregates
 //   opt.cpp:1179-1195 get_magnitude after optimisation
 //   main.cpp:74-101   TrainingKernels(params, density) + the predict_distribution lambda
+//   main.cpp:140-143  evolve(density, ...), evolve(extra_points, ...), is_very_small(...) with the kernels in place of the lambda (host/evolve.h)
+//   mc.cpp:118-165, 349-369  the Metropolis walk of an element's points (host/mc.h)
 //   output.cpp:181-233, 262-290  output_phase over the grid, rescale factors in the log line
 #include "stdafx.h"
 
+#include "evolve.h"
+#include "mc.h"
 #include "predict.h"
 #include "storage.h"
 
@@ -205,6 +209,49 @@ int main(int argc, char** argv)
 	std::printf("mean_r %.17g %.17g\npopulation_0 %.17g\n", mean_r[0], mean_r[1], calculate_population_one_surface((*all_kernels)(0).value()));
 	// output.cpp:262-290
 	std::printf("rescale %.17g %.17g\n", (*all_kernels)(0)->get_rescale_factor(), (*all_kernels)(1, 0)->get_rescale_factor());
+
+	// main.cpp:140-143: the tick's three calls, the kernels standing where predict_distribution stood (two-level system: what the
+	// reference instantiates, evolve.cpp:367-371)
+	if constexpr (NumPES == 2)
+	{
+		ClassicalVector<double> mass;
+		mass[0] = 2000.0;
+		const double dt = 1.0;
+		AllPoints moved = density, moved_extra = extra;
+		evolve(moved, mass, dt, *all_kernels);
+		evolve(moved_extra, mass, dt, *all_kernels);
+		for (std::size_t iPES = 0; iPES < NumPES; iPES++)
+			for (std::size_t jPES = 0; jPES <= iPES; jPES++)
+			{
+				std::printf("evolve_%zu%zu", iPES, jPES);
+				for (const PhaseSpacePoint& psp : moved(iPES, jPES))
+				{
+					const auto& [r, rho] = psp;
+					std::printf(" %.17g %.17g %.17g %.17g", r[0], r[1], rho.real(), rho.imag());
+				}
+				std::printf("\n");
+			}
+		std::printf("evolve_extra_sizes %zu %zu %zu\n", moved_extra(0).size(), moved_extra(1, 0).size(), moved_extra(1).size());
+		const QuantumStorage<bool> IsSmall = is_very_small(density, mass, dt, *all_kernels);
+		std::printf("is_small %d %d %d\n", IsSmall(0) ? 1 : 0, IsSmall(1, 0) ? 1 : 0, IsSmall(1) ? 1 : 0);
+		const std::complex<double> np = new_point_predict(r0, mass, dt, *all_kernels, 1, 1);
+		std::printf("new_point_11 %.17g %.17g\n", np.real(), np.imag());
+		// mc.cpp:118-165 for all points of rho_00 at once, then the selection body of mc.cpp:349-369
+		EigenVector<ClassicalPhaseVector> start;
+		for (const PhaseSpacePoint& psp : density(0)) start.push_back(psp.get<0>());
+		const auto [last, ratio] = gple_host::generate_markov_chain(25, *all_kernels, 0.3, 0, 0, start, 0xC0FFEE1234ULL);
+		std::printf("chain_last");
+		for (const ClassicalPhaseVector& r : last) std::printf(" %.17g %.17g", r[0], r[1]);
+		std::printf("\nchain_ratio");
+		for (double a : ratio) std::printf(" %.17g", a);
+		std::printf("\n");
+		ElementPoints walked = density(0);
+		MCParameters mcp(25, 0.3);
+		gple_host::element_monte_carlo_walk(walked, mcp, *all_kernels, 0, 0, 0xC0FFEE1234ULL);
+		std::printf("walk_rho");
+		for (const PhaseSpacePoint& psp : walked) std::printf(" %.17g", psp.get<1>().real());
+		std::printf("\nwalk_same_points %d\n", std::equal(walked.begin(), walked.end(), last.begin(), [](const PhaseSpacePoint& a, const ClassicalPhaseVector& b) { return a.get<0>() == b; }) ? 1 : 0);
+	}
 
 	// evolve.cpp:392-420, mc.cpp:214-246: the same lambda from several worker threads at once (std::thread standing in for TBB);
 	// every thread must get what the lone call returns, and the calls per second are printed for one and for eight threads

@@ -137,3 +137,34 @@ def test_panel_step_reports_a_non_positive_pivot(gpu, pend):
     assert np.isnan(T[64:128, 64:128]).any() and np.isnan(A[128:, 64:128]).any()
     lo = bad // 16 * 16  # NaN spreads through the 16 x 16 tile products of its own sub-panel; the rows above it never see it
     assert np.all(np.isfinite(T[64:64 + lo, 64:64 + lo]))
+
+
+@pytest.mark.parametrize("pre", [0, 1, 2, 3, 4, 5])
+def test_side_stream_lands_on_its_own_hardware_queue(pre):
+    """The fit's side stream (block-row inverse beside the panels, n >= 1024) must not share the main stream's hardware queue.  HIP binds
+    streams to GPU_MAX_HW_QUEUES (4) queues by use count as they are created, so whether a fresh stream collides depends on how many streams
+    the process holds already — here `pre` of them are created (and used) first, and for every count the context must end up with a side stream
+    whose probe kernels ran beside the main stream's (csrc/gple_chol.hip, pick_side_stream).  Measured without the probing: N = 4096 fit
+    2.0 -> 2.4 / 3.9 ms on a collision (profiles/r03_notes.md)."""
+    import torch
+
+    import gaussian_process_liouville_equation_amd as pkg
+    from tests.test_gpu_configs import config_inputs, THETA_R
+    keep = []
+    for _ in range(pre):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            keep.append(torch.zeros(16, device="cuda") + 1)
+        keep.append(s)
+    torch.cuda.synchronize()
+    api = pkg.open_api(0)
+    try:
+        X, y, _, _ = config_inputs(1024, 8, 1)
+        f = api.real_fit(THETA_R, X, y, 3)
+        assert f.scalars["info"] == 0
+        attempts, overlaps = ctypes.c_int(), ctypes.c_int()
+        assert api.lib.gple_debug_side_stream(api.ctx, ctypes.byref(attempts), ctypes.byref(overlaps)) == 0
+        assert 1 <= attempts.value <= 8 and overlaps.value == 1, (pre, attempts.value, overlaps.value)
+        f.release()
+    finally:
+        api.close()

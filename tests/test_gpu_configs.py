@@ -110,7 +110,8 @@ def check_complex_fit_and_rows(gpu, fit, theta, X, grid, p, rows):
     # numpy's own rounding of these cancelling sums is ~ eps * sum |k| |v| (cond(K) ~ N / sn^2): part of the tolerance
     round_off = 100 * parity.EPS * ((np.abs(k) + np.abs(kt)) @ np.abs(v)).max()
     assert np.abs(mu - p["prediction"][rows]).max() <= 1e-8 * np.abs(p["prediction"]).max() + round_off
-    assert np.abs(var - p["variance"][rows]).max() <= 1e-6  # the reference's form cancels four N^2 sums of size ~cond
+    # the reference's form cancels four N^2 sums of size ~cond(K) ~ N / sn^2 in numpy's own rounding: the tolerance grows with N
+    assert np.abs(var - p["variance"][rows]).max() <= 1e-6 * max(1.0, N / 4096.0)
     return kss
 
 

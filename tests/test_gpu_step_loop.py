@@ -283,8 +283,10 @@ def test_tick_at_c5_size(gpu):
             r = rng.normal([xc, 14.112], [0.7086, 0.7056], size=(n, 2))
             g = np.exp(-0.5 * (((r[:, 0] - xc) / 0.7086) ** 2 + ((r[:, 1] - 14.112) / 0.7056) ** 2)) / (2 * np.pi * 0.7086 * 0.7056)
             store[(i, j)] = (r, (g * (0.6, 0.3 * np.exp(0.4j * (r[:, 0] - xc)), 0.4)[e]).astype(complex))
-    thc = [1.0, 1.0, 0.7086, 0.7056, 1.0, 0.7086, 0.7056, 1e-2]
-    params = {(0, 0): TH, (1, 0): thc, (1, 1): TH}
+    # complex hyper-parameters with distinct sub-kernels: at the reference's INITIAL ones (opt.cpp:306-332: sR = sI, lR = lI) the pseudo-covariance
+    # 2i K_C equals the covariance K_R + K_I in modulus, the widely-linear model degenerates to labels of fixed phase, and one tick of
+    # back-propagation against that fit halves |rho_10| (purity 0.61 -> 0.55 on the oracle as well, N = 300) — the optimiser moves away from them
+    params = {(0, 0): TH, (1, 0): THC, (1, 1): TH}
     k0 = K.TrainingKernels(params, K.construct_training_sets(dens), True, True, False, api=gpu)
     pop0, pur0 = k0.calculate_population(), k0.calculate_purity()
     assert abs(pop0 - 1.0) <= 0.02
@@ -295,8 +297,8 @@ def test_tick_at_c5_size(gpu):
         # one classical step: dx = p dt / m up to the force's second-order term
         assert np.abs(d1[e][0][:, 0] - dens[e][0][:, 0] - dens[e][0][:, 1] * DT / MASS).max() <= 1e-3
     pop1, pur1 = k1.calculate_population(), k1.calculate_purity()
-    assert abs(pop1 - pop0) <= 0.05 * abs(pop0), (pop0, pop1)
-    assert abs(pur1 - pur0) <= 0.10 * abs(pur0), (pur0, pur1)
+    assert abs(pop1 - pop0) <= 0.02 * abs(pop0), (pop0, pop1)
+    assert abs(pur0 - 0.70) <= 0.02 and abs(pur1 - pur0) <= 0.03 * abs(pur0), (pur0, pur1)  # 2 pi int (0.36 + 0.16 + 2 * 0.09) g^2 = 0.70
     # spot check: the same tick for 8 points per element alone
     idx = rng.choice(N, 8, replace=False)
     sub = {e: (dens[e][0][idx], dens[e][1][idx]) for e in dens}
