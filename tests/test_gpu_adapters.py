@@ -66,6 +66,38 @@ def test_reference_call_patterns_through_the_adapters(gpu, oracle):
     for k in ("point_10", "batch_10", "pointwise_10"):
         assert close(got[k], [p10.real, p10.imag], 1e-6), k
     assert np.all(got["point_last"] == 0) and np.all(got["batch_last"] == 0)  # element without a kernel (main.cpp:86-88)
+    # main.cpp:140-143 through host/evolve.h: evolve(density, mass, dt, *all_kernels), is_very_small, new_point_predict against the numpy
+    # restatement of evolve.cpp with the C++ oracle's predictor as its DistributionFunction
+    from oracle import evolve_oracle as E
+
+    def distribution(pts, i, j):
+        k = ko(i, j) if i != j else ko(i)
+        if k is None:
+            return np.zeros(len(pts), dtype=complex)
+        pred = oracle.complex_predict if i != j else oracle.real_predict
+        return np.asarray(pred(k._fit, pts, want=("cutoff",))["cutoff"], dtype=complex)
+
+    ref = E.evolve(dens, 2000.0, 1.0, distribution, E.DAC)
+    for (i, j) in K.element_order(2):
+        line = got[f"evolve_{i}{j}"].reshape(-1, 4)
+        assert len(line) == len(dens[(i, j)][0])
+        if len(line):
+            assert np.abs(line[:, :2] - ref[(i, j)][0]).max() <= 1e-12 * np.abs(ref[(i, j)][0]).max()
+            rho = line[:, 2] + 1j * line[:, 3]
+            assert np.abs(rho - ref[(i, j)][1]).max() <= 1e-8 * np.abs(ref[(i, j)][1]).max(), (i, j)
+    assert list(got["evolve_extra_sizes"]) == [2 * N, 2 * N, 0]
+    small = E.is_very_small(dens, 2000.0, 1.0, distribution, E.DAC)
+    assert list(got["is_small"]) == [int(small[(0, 0)]), int(small[(1, 0)]), int(small[(1, 1)])] and got["is_small"][0] == 0
+    npo = E.new_point_predict(r0, 2000.0, 1.0, distribution, 1, 1, E.DAC)[0]
+    assert abs(complex(*got["new_point_11"]) - npo) <= 1e-8 * max(abs(npo), 1e-3 * abs(p00))
+    # mc.cpp:118-165 / 349-369 through host/mc.h: same Philox stream, same decisions as the oracle's walkers
+    ro, ao = E.generate_markov_chain(25, distribution, 0.3, 0, 0, dens[(0, 0)][0], 0xC0FFEE1234)
+    last = got["chain_last"].reshape(-1, 2)
+    same = np.abs(last - ro).max(axis=1) <= 1e-12
+    assert same.mean() >= 0.95 and np.abs(got["chain_ratio"][same] - ao[same]).max() <= 1e-15
+    assert got["walk_same_points"][0] == 1
+    wr = distribution(last, 0, 0).real
+    assert np.abs(got["walk_rho"] - wr).max() <= 1e-7 * np.abs(wr).max()
     assert np.array_equal(got["point_00"], got["batch_00"]) and np.array_equal(got["point_10"], got["batch_10"])
     # the point-wise lambda from eight threads at once: same values, and not slower than one thread (requests ride together)
     assert np.all(got["threads_same"] == 1)
