@@ -225,6 +225,8 @@ def main():
                          "'torch' = parallel.GridShardedStep with torch.distributed.all_gather_into_tensor (the A/B, and the gloo rehearsal)")
     ap.add_argument("--comm-at-one", action="store_true", help="--gpus 1 --via capi: still create a one-rank ncclComm_t and go through the all-gather path")
     ap.add_argument("--plan", default="auto", choices=["auto", "elements", "grid", "hybrid"], help="--workload C4 | C5: force one of the planner's candidates")
+    ap.add_argument("--opt-only", type=int, default=None, choices=[0, 1, 2],
+                    help="--workload C4opt: evaluate only element i (0, 2: real; 1: complex) — its derivative GEMMs then have the GPU to themselves")
     ap.add_argument("--shard", default="grid", choices=["grid", "elements"],
                     help="--gpus > 1: 'grid' (default) = strong scaling of ONE element's step, the grid prediction split over the "
                          "ranks and all-gathered; 'elements' = weak scaling over the independent density-matrix elements, every "
@@ -715,7 +717,7 @@ def opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev):
     from gaussian_process_liouville_equation_amd import kernels as K
     N = WORKLOADS["C4opt"][0]
     elems = [("real", 0), ("complex", 1), ("real", 2)]  # reference order (0,0), (1,0), (1,1)
-    mine = [i for i in range(3) if parallel.element_owner(i, world) == rank]
+    mine = [i for i in range(3) if parallel.element_owner(i, world) == rank and args.opt_only in (None, i)]
     pool = K.ApiPool(n=max(1, len(mine)), device=dev)
     objs, thetas = {}, {}
     for slot, i in enumerate(mine):
@@ -769,17 +771,20 @@ def opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev):
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     # SURVEY.md §8(d) minimum-work gradient model per element: F_grad = 2 D n^3 + 2 n^3 (D = 2 length parameters; real n = N).
     # The complex element in the [Re; Im] embedding runs 6 GEMMs of size 2N.
-    F_eval = sum((6 if k == "complex" else 2) * 2.0 * ((2 * N if k == "complex" else N) ** 3) + ((2 * N if k == "complex" else N) ** 3) for k, _ in elems)
+    F_eval = sum((6 if k == "complex" else 2) * 2.0 * ((2 * N if k == "complex" else N) ** 3) + ((2 * N if k == "complex" else N) ** 3) for k, i in elems
+                 if args.opt_only in (None, i))
     result = {
         "metric": "GP fit+predict ms/step (N samples, M grid pts)", "value": round(ms, 4), "unit": "ms/step", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"C4opt: opt.cpp inner loop, full_loose value+gradient of 2 real + 1 complex element, N={N}, 5N={5 * N} extra points each",
-                   "N": N, "M": 5 * N, "parallelism": "3 elements on 3 HIP streams of one GPU" if world == 1 else f"elements dealt out over {world} ranks, scalars all-reduced"},
+                   "N": N, "M": 5 * N, "parallelism": ("3 elements on 3 HIP streams of one GPU" if args.opt_only is None else f"element {args.opt_only} alone") if world == 1 else f"elements dealt out over {world} ranks, scalars all-reduced"},
         "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<128,128> (dK * K^-1 of the LOOCV gradient, kernel.cpp:354)", "achieved": round(achieved, 3),
-                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
+                     "traffic": traffic_for("C4opt" if args.opt_only is None else f"C4opt_only{args.opt_only}", world)[0],
                      "kernel_ms": round(gemm_ms / max(1, gemm_cnt), 4), "launches_per_step": gemm_cnt / max(1, args.steps),
-                     "note": "the three elements run concurrently on one GPU, so a GEMM's event time includes what it shares with the other streams"},
+                     "note": ("the three elements run concurrently on one GPU, so a GEMM's event time includes what it shares with the other streams"
+                              if args.opt_only is None else f"element {args.opt_only} alone: its GEMMs have the GPU to themselves")},
         "mfma_frac_step": round(F_eval / (ms * 1e-3) / (FP64_PEAK_TFLOPS * 1e12), 4),
         "phases_ms": per_elem,
     }

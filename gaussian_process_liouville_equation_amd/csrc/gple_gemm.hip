@@ -18,6 +18,8 @@
 #include <cstdlib>
 
 #include "gple_internal.h"
+#include <cstdio>
+#include <mutex>
 
 namespace gple
 {
@@ -483,13 +485,39 @@ namespace gple
 		return (m / 128) * (n / 128) * batch >= (triangular ? min_tri : min_dense) ? 128 : 64;
 	}
 
+	// GPLE_GEMM_LOG=<file>: one line per launch — stream, tile, M N K batch krange lower_only and the algorithmic flops of the computed
+	// tiles' k-ranges — in launch order.  probes/fit_kernel_table.py matches the lines with a rocprofv3 kernel trace of the same run
+	// (per stream the order is the same) and prints TFLOP/s per kernel family.  Diagnostic only: nothing is logged without the variable.
+	static void log_gemm(hipStream_t s, const GemmDesc& d, int tile)
+	{
+		static FILE* const f = [] {
+			const char* path = getenv("GPLE_GEMM_LOG");
+			return path ? fopen(path, "w") : nullptr;
+		}();
+		if (!f) return;
+		// k-range of the tile at (m0, n0), as the kernels take it (rounded to whole tiles)
+		double flops = 0.0;
+		for (int m0 = 0; m0 < d.M; m0 += tile)
+			for (int n0 = 0; n0 < d.N; n0 += tile)
+			{
+				if (d.lower_only && m0 + tile <= n0) continue;
+				int k0 = 0, k1 = d.K;
+				if (d.krange == K_GE_N) k0 = n0;
+				else if (d.krange == K_LE_M) k1 = std::min(d.K, m0 + tile);
+				else if (d.krange == K_GE_MAX_MN) k0 = std::max(m0, n0);
+				if (k1 > k0) flops += 2.0 * tile * tile * (k1 - k0);
+			}
+		static std::mutex mu;
+		std::lock_guard<std::mutex> lk(mu);
+		fprintf(f, "%p %d %d %d %d %d %d %d %.0f\n", static_cast<void*>(s), tile, d.M, d.N, d.K, d.batch, d.krange, d.lower_only, flops * d.batch);
+		fflush(f);
+	}
+
 	hipError_t launch_gemm(hipStream_t s, const GemmDesc& d, int tile)
 	{
-		if (tile == 32)
-		{
-			if (!d.c_trans && !d.a_kmajor) return launch_splitk(s, d);
-			tile = 64; // operand layouts the split-k kernel is not instantiated for
-		}
+		if (tile == 32 && (d.c_trans || d.a_kmajor)) tile = 64; // operand layouts the split-k kernel is not instantiated for
+		log_gemm(s, d, tile);
+		if (tile == 32) return launch_splitk(s, d);
 		return tile == 128 ? launch_tile<128>(s, d) : launch_tile<64>(s, d);
 	}
 } // namespace gple
