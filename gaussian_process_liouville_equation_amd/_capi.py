@@ -127,6 +127,36 @@ def objective_minimize_neldermead(lib, objectives, x0, lb, ub, maxeval=0):
     return list(x), f.value, ne.value
 
 
+def minimize_direct_l(lib, fun, x0, lb, ub, maxeval=0):
+    """the library's DIRECT-L (gple_minimize_direct_l, the GN_DIRECT_L stand-in) on a Python objective fun(x list) -> float; (x, f, n_eval)"""
+    n = len(x0)
+    cb = OBJECTIVE_FN(lambda nn, xp, gp, data: float(fun([xp[i] for i in range(nn)])))
+    x, lbv, ubv = _f64(x0).copy(), _f64(lb), _f64(ub)
+    f, ne = C.c_double(), C.c_int()
+    lib.gple_minimize_direct_l.argtypes = [OBJECTIVE_FN, C.c_void_p, C.c_uint, _dp, _dp, C.POINTER(OptOptions), _dp, _dp, C.POINTER(C.c_int)]
+    st = lib.gple_minimize_direct_l(cb, None, n, _ptr(lbv), _ptr(ubv), C.byref(_opt_options(maxeval)), _ptr(x), C.cast(C.byref(f), _dp), C.byref(ne))
+    if st != GPLE_OK:
+        raise GpleError(f"gple_minimize_direct_l: status {st}")
+    return list(x), f.value, ne.value
+
+
+def objective_minimize_direct_l(lib, objectives, x0, lb, ub, is_log=None, maxeval=0):
+    """gple_objective_minimize_direct_l over resident objectives (same data, different contexts): the new rectangle centres of an iteration
+    are evaluated concurrently; is_log flags the coordinates that are logarithms of their parameter (the global tier's reparametrisation)"""
+    n = len(x0)
+    arr = (C.c_void_p * len(objectives))(*[o.handle.value for o in objectives])
+    x, lbv, ubv = _f64(x0).copy(), _f64(lb), _f64(ub)
+    flags = (C.c_ubyte * n)(*[1 if (is_log is not None and is_log[i]) else 0 for i in range(n)])
+    f, ne = C.c_double(), C.c_int()
+    lib.gple_objective_minimize_direct_l.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, _dp, _dp, C.POINTER(C.c_ubyte), C.POINTER(OptOptions), _dp, _dp,
+                                                     C.POINTER(C.c_int)]
+    st = lib.gple_objective_minimize_direct_l(arr, len(objectives), n, _ptr(lbv), _ptr(ubv), flags, C.byref(_opt_options(maxeval)), _ptr(x), C.cast(C.byref(f), _dp),
+                                              C.byref(ne))
+    if st != GPLE_OK:
+        raise GpleError(f"gple_objective_minimize_direct_l: status {st}")
+    return list(x), f.value, ne.value
+
+
 class Points(C.Structure):
     """gple_points: the selected phase-space points of one density-matrix element"""
     _fields_ = [("r", C.POINTER(C.c_double)), ("rho", C.POINTER(C.c_double)), ("n", C.c_size_t)]
@@ -174,7 +204,7 @@ GPLE_SYMBOLS = [
     "real_gram", "complex_gram", "cutoff_factor", "predict_batch", "shard_bounds", "set_allgather_function", "real_predict_sharded", "complex_predict_sharded", "real_predict_dealt", "complex_predict_dealt", "deal_share",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
-    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "minimize_neldermead", "objective_minimize_neldermead", "minimize_auglag_eq", "pes_adiabatic", "evolve", "markov_chain", "markov_chain_trace", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
+    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "minimize_neldermead", "objective_minimize_neldermead", "minimize_direct_l", "objective_minimize_direct_l", "minimize_auglag_eq", "pes_adiabatic", "evolve", "markov_chain", "markov_chain_trace", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
 ]
 
 

@@ -9,6 +9,12 @@
 //   * augmented Lagrangian for equality constraints (Conn, Gould, Toint 1991 / Birgin & Martinez 2008, the scheme NLopt's
 //     AUGLAG_EQ follows): minimise f + sum lambda_i h_i + rho / 2 sum h_i^2 in the box, lambda += rho h, rho *= 10 when the
 //     infeasibility did not shrink to a quarter; inner solver: projected BFGS with Armijo backtracking.
+//   * DIRECT-L (Jones, Perttunen, Stuckman 1993; Gablonsky & Kelley 2001, "A locally-biased form of the DIRECT algorithm") for the
+//     global tier (GN_DIRECT_L, opt.h:54, opt.cpp:336, 1344-1365): rectangles measured by their longest side, one rectangle per
+//     size on the lower hull, every longest side trisected in the order of the better of its two new values — the variant and
+//     the settings NLopt's cdirect runs for GN_DIRECT_L (epsilon = 0; stop when an iteration improves the minimum by less than
+//     ftol, when every rectangle divided in an iteration is below xtol, or at maxeval).  All new centres of an iteration are
+//     independent: they form ONE batch, which the resident-objective form spreads over its contexts.
 // Iterates differ from NLopt's (as any two implementations' do); tolerances, stopping tests and the callback ABIs are kept.
 // gple_objective_minimize_neldermead evaluates the simplex vertices CONCURRENTLY on several resident objectives (one context =
 // one HIP stream each): the n + 1 start vertices, and per iteration the reflected, expanded and both contracted points
@@ -18,7 +24,9 @@
 #include <functional>
 #include <future>
 #include <limits>
+#include <map>
 #include <numeric>
+#include <set>
 #include <vector>
 
 #include "../../include/gple.h"
@@ -254,8 +262,216 @@ namespace
 	}
 } // namespace
 
+namespace
+{
+	// DIRECT-L on the free coordinates of the box, scaled to the unit cube (as NLopt's cdirect wrapper does).
+	int direct_l(const BatchEval& eval, unsigned n, const Box& box, const gple_opt_options& opt, double* x, double* fmin, int* n_eval)
+	{
+		const int nf = static_cast<int>(box.free.size());
+		std::vector<double> x0(x, x + n);
+		for (unsigned i = 0; i < n; ++i) x0[i] = clip(x0[i], box.lb[i], box.ub[i]);
+		for (int k = 0; k < nf; ++k)
+			if (!std::isfinite(box.lb[box.free[k]]) || !std::isfinite(box.ub[box.free[k]])) return GPLE_ERR_BAD_ARG; // DIRECT needs a finite box
+		int evals = 0;
+		auto to_full = [&](const std::vector<double>& u) {
+			std::vector<double> full = x0;
+			for (int k = 0; k < nf; ++k) full[box.free[k]] = box.lb[box.free[k]] + u[k] * (box.ub[box.free[k]] - box.lb[box.free[k]]);
+			return full;
+		};
+		auto evaluate = [&](const std::vector<std::vector<double>>& us) {
+			std::vector<std::vector<double>> pts;
+			for (const auto& u : us) pts.push_back(to_full(u));
+			std::vector<double> vals(pts.size());
+			eval(pts, vals);
+			evals += static_cast<int>(pts.size());
+			for (double& v : vals)
+				if (!std::isfinite(v)) v = std::numeric_limits<double>::max(); // make_normal, opt.cpp:420-431
+			return vals;
+		};
+		if (nf == 0)
+		{
+			*fmin = evaluate({{}})[0];
+			std::copy(x0.begin(), x0.end(), x);
+			if (n_eval) *n_eval = evals;
+			return GPLE_OK;
+		}
+		struct Rect
+		{
+			std::vector<double> c, w; // centre and widths in the unit cube
+			double f;
+		};
+		std::vector<Rect> rects;
+		// size class (longest side / 2, rounded to float so that equal sizes compare equal) -> its rectangles by (value, age)
+		std::map<float, std::set<std::pair<double, int>>> classes;
+		constexpr double EQUAL_SIDE_TOL = 5e-2;
+		auto diameter = [&](const Rect& r) { return static_cast<float>(0.5 * *std::max_element(r.w.begin(), r.w.end())); };
+		auto insert = [&](Rect r) {
+			rects.push_back(std::move(r));
+			classes[diameter(rects.back())].insert({rects.back().f, static_cast<int>(rects.size()) - 1});
+		};
+		std::vector<double> best_u(nf, 0.5);
+		{
+			Rect r{std::vector<double>(nf, 0.5), std::vector<double>(nf, 1.0), 0.0};
+			r.f = evaluate({r.c})[0];
+			insert(r);
+		}
+		double best = rects[0].f;
+		const int budget = opt.max_eval > 0 ? opt.max_eval : 100000; // MaximumEvaluations, opt.cpp:339
+		// width below which a side counts as converged: xtol_abs is given in the caller's units
+		auto is_small = [&](const Rect& r) {
+			for (int k = 0; k < nf; ++k)
+			{
+				const double span = box.ub[box.free[k]] - box.lb[box.free[k]];
+				if (!(r.w[k] <= opt.xtol_abs / span || r.w[k] <= opt.xtol_rel)) return false;
+			}
+			return true;
+		};
+		int status = GPLE_OK;
+		while (evals < budget)
+		{
+			// 1. potentially optimal rectangles: the best of every size class, then the lower-right convex hull from the class that holds the
+			// overall minimum to the largest class (epsilon = 0: every hull point right of the minimum qualifies)
+			std::vector<std::pair<float, std::pair<double, int>>> cls;
+			for (const auto& [d, members] : classes)
+				if (!members.empty()) cls.push_back({d, *members.begin()});
+			size_t kmin = 0;
+			for (size_t k = 0; k < cls.size(); ++k)
+				if (cls[k].second.first <= cls[kmin].second.first) kmin = k; // ties: the larger rectangle
+			std::vector<size_t> hull;
+			for (size_t k = kmin; k < cls.size(); ++k)
+			{
+				while (hull.size() >= 2)
+				{
+					const auto &a = cls[hull[hull.size() - 2]], &b = cls[hull.back()], &c = cls[k];
+					// b lies on or above the segment a - c: not on the lower hull
+					const double cross = (static_cast<double>(b.first) - a.first) * (c.second.first - a.second.first)
+						- (b.second.first - a.second.first) * (static_cast<double>(c.first) - a.first);
+					if (cross <= 0.0) hull.pop_back();
+					else break;
+				}
+				hull.push_back(k);
+			}
+			// 2. every longest side of every selected rectangle gets its two new centres; all of them are one batch
+			struct Plan
+			{
+				int id;
+				std::vector<int> sides;
+			};
+			std::vector<Plan> plans;
+			std::vector<std::vector<double>> batch;
+			for (size_t h : hull)
+			{
+				const int id = cls[h].second.second;
+				const Rect& r = rects[id];
+				const double wmax = *std::max_element(r.w.begin(), r.w.end());
+				Plan pl{id, {}};
+				for (int k = 0; k < nf; ++k)
+					if (wmax - r.w[k] <= wmax * EQUAL_SIDE_TOL) pl.sides.push_back(k);
+				for (int k : pl.sides)
+					for (int sgn : {+1, -1})
+					{
+						std::vector<double> u = r.c;
+						u[k] += sgn * r.w[k] / 3.0;
+						batch.push_back(std::move(u));
+					}
+				plans.push_back(std::move(pl));
+			}
+			if (batch.empty()) break;
+			const std::vector<double> vals = evaluate(batch);
+			// 3. divide: sides in the order of the better of their two values (the best new points end up in the largest new rectangles)
+			const double best_before = best;
+			bool all_small = true;
+			size_t q = 0;
+			for (const Plan& pl : plans)
+			{
+				const size_t base = q;
+				q += 2 * pl.sides.size();
+				std::vector<size_t> order(pl.sides.size());
+				std::iota(order.begin(), order.end(), size_t(0));
+				std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+					return std::min(vals[base + 2 * a], vals[base + 2 * a + 1]) < std::min(vals[base + 2 * b], vals[base + 2 * b + 1]);
+				});
+				Rect parent = rects[pl.id];
+				classes[diameter(parent)].erase({parent.f, pl.id});
+				for (size_t o : order)
+				{
+					const int k = pl.sides[o];
+					const double third = parent.w[k] / 3.0;
+					parent.w[k] = third;
+					for (int sgn = 0; sgn < 2; ++sgn)
+					{
+						Rect child{parent.c, parent.w, vals[base + 2 * o + sgn]};
+						child.c[k] += (sgn == 0 ? +1.0 : -1.0) * third;
+						if (child.f < best) best = child.f, best_u = child.c;
+						insert(std::move(child));
+					}
+				}
+				rects[pl.id] = parent;
+				classes[diameter(parent)].insert({parent.f, pl.id});
+				all_small = all_small && is_small(parent);
+			}
+			// 4. NLopt's stopping rules for cdirect: xtol on the rectangles just divided, ftol on an iteration that improved the minimum
+			if (all_small) break;
+			if (best < best_before)
+			{
+				const double df = std::fabs(best - best_before);
+				if (df < opt.ftol_abs || df < opt.ftol_rel * 0.5 * (std::fabs(best) + std::fabs(best_before))) break;
+			}
+		}
+		const std::vector<double> full = to_full(best_u);
+		std::copy(full.begin(), full.end(), x);
+		*fmin = best;
+		if (n_eval) *n_eval = evals;
+		return status;
+	}
+} // namespace
+
 extern "C"
 {
+	int gple_minimize_direct_l(gple_objective_fn f, void* data, unsigned n, const double* lb, const double* ub, const gple_opt_options* options, double* x,
+		double* fmin, int* n_eval)
+	{
+		if (!f || !x || !fmin || n == 0 || !lb || !ub) return GPLE_ERR_BAD_ARG;
+		const Box box = make_box(n, lb, ub);
+		const BatchEval eval = [&](const std::vector<std::vector<double>>& pts, std::vector<double>& vals) {
+			for (size_t i = 0; i < pts.size(); ++i) vals[i] = f(n, pts[i].data(), nullptr, data);
+		};
+		return direct_l(eval, n, box, defaults(options), x, fmin, n_eval);
+	}
+
+	int gple_objective_minimize_direct_l(gple_objective* const* objectives, size_t n_objectives, size_t n, const double* lb, const double* ub,
+		const unsigned char* is_log, const gple_opt_options* options, double* x, double* fmin, int* n_eval)
+	{
+		if (!objectives || n_objectives == 0 || !x || !fmin || !lb || !ub || (n != 4 && n != 8)) return GPLE_ERR_BAD_ARG;
+		for (size_t i = 0; i < n_objectives; ++i)
+			if (!objectives[i]) return GPLE_ERR_BAD_ARG;
+		const Box box = make_box(static_cast<unsigned>(n), lb, ub);
+		int status = GPLE_OK;
+		// loose_function_global_wrapper (opt.cpp:489-497): coordinates flagged in is_log are logarithms of the parameters they stand for
+		const BatchEval eval = [&](const std::vector<std::vector<double>>& pts, std::vector<double>& vals) {
+			std::vector<std::future<int>> jobs;
+			for (size_t w = 0; w < std::min(n_objectives, pts.size()); ++w)
+				jobs.push_back(std::async(std::launch::async, [&, w] {
+					int st = GPLE_OK;
+					std::vector<double> theta(n);
+					for (size_t q = w; q < pts.size(); q += n_objectives)
+					{
+						for (size_t i = 0; i < n; ++i) theta[i] = is_log && is_log[i] ? std::exp(pts[q][i]) : pts[q][i];
+						const int s = gple_objective_eval(objectives[w], theta.data(), n, &vals[q], nullptr);
+						if (s != GPLE_OK) st = s, vals[q] = std::numeric_limits<double>::max();
+					}
+					return st;
+				}));
+			for (auto& j : jobs)
+			{
+				const int s = j.get();
+				if (s != GPLE_OK) status = s;
+			}
+		};
+		const int rc = direct_l(eval, static_cast<unsigned>(n), box, defaults(options), x, fmin, n_eval);
+		return rc != GPLE_OK ? rc : status;
+	}
+
 	int gple_minimize_neldermead(gple_objective_fn f, void* data, unsigned n, const double* lb, const double* ub, const gple_opt_options* options, double* x,
 		double* fmin, int* n_eval)
 	{

@@ -5,8 +5,8 @@
 // from opt.cpp: the parameter layout, the bounds (:33-104, 394-413, 1027-1047), the log reparametrisation of the global tier
 // (:109-232), make_normal (:420-431), the element-wise -> diagonal -> full sequence (:1101-1198), the previous / initial /
 // global tiers with check_averages and compare_and_overwrite (:1200-1392).  What differs: the iterates of the searches (any two
-// implementations' do), and the global tier, which restarts the derivative-free search from a deterministic set of points in the
-// log-parameter box instead of running DIRECT-L.  The algorithm arguments of the reference's constructor are accepted and ignored.
+// implementations' do).  The global tier runs the library's DIRECT-L (gple_objective_minimize_direct_l) where the reference runs NLopt's
+// GN_DIRECT_L.  The algorithm arguments of the reference's constructor are accepted and ignored.
 #ifndef OPT_H
 #define OPT_H
 
@@ -219,8 +219,9 @@ private:
 				}
 			return Result(total_error, num_steps, Default);
 		}
-		/// the global tier's element-wise stage (opt.cpp:1344-1365): the same objective in log-parameters (:489-497), restarted
-		/// from a deterministic set of points of the box; pv in, pv out in normal parameters
+		/// the global tier's element-wise stage (opt.cpp:1344-1365): GN_DIRECT_L (opt.h:54) on the same objective in log-parameters
+		/// (loose_function_global_wrapper, :489-497) — the library's DIRECT-L on the resident objective, MaximumEvaluations and the
+		/// tolerances of opt.cpp:339-350; pv in, pv out in normal parameters
 		std::vector<std::size_t> global_elementwise(QuantumStorage<ParameterVector>& pv) const
 		{
 			std::vector<std::size_t> num_steps;
@@ -234,51 +235,25 @@ private:
 					}
 					const std::size_t n = width(iPES, jPES);
 					const std::vector<std::size_t> logs = log_indices(n);
+					std::vector<unsigned char> is_log(n, 0);
+					for (std::size_t i : logs) is_log[i] = 1;
 					auto to_global = [&logs](ParameterVector v) {
 						for (std::size_t i : logs) v[i] = std::log(v[i]);
 						return v;
 					};
 					const Bounds& b = self.ParameterBounds(iPES, jPES);
 					const ParameterVector lb = to_global(b[0]), ub = to_global(b[1]);
-					struct Wrapped
+					ParameterVector x = to_global(pv(iPES, jPES));
+					gple_objective* obj = objectives(iPES, jPES);
+					const gple_opt_options opt{1e-5, 1e-5, 1e-15, 1e-15, 0.5, 100000}; // MaximumEvaluations, opt.cpp:339
+					double fx = 0.0;
+					int n_eval = 0;
+					if (gple_objective_minimize_direct_l(&obj, 1, n, lb.data(), ub.data(), is_log.data(), &opt, x.data(), &fx, &n_eval) == GPLE_OK)
 					{
-						const Session* s;
-						std::size_t i, j;
-						const std::vector<std::size_t>* logs;
-					} wrapped{this, iPES, jPES, &logs};
-					const gple_objective_fn f = [](unsigned nn, const double* x, double*, void* data) -> double
-					{
-						const Wrapped& w = *static_cast<const Wrapped*>(data);
-						ParameterVector local(x, x + nn);
-						for (std::size_t i : *w.logs) local[i] = std::exp(local[i]); // global_parameter_to_local, opt.cpp:197-232
-						double v = w.s->element_loose(w.i, w.j, local.data(), nullptr);
-						make_normal(v);
-						return v;
-					};
-					gple_opt_options opt{1e-5, 1e-5, 1e-15, 1e-15, 0.5, 200};
-					ParameterVector best = to_global(pv(iPES, jPES));
-					double best_f = std::numeric_limits<double>::max();
-					std::size_t evals = 0;
-					const unsigned primes[8] = {2, 3, 5, 7, 11, 13, 17, 19};
-					for (unsigned start = 0; start < 9; start++) // the current point, then 8 Halton points of the box
-					{
-						ParameterVector x = to_global(pv(iPES, jPES));
-						if (start > 0)
-							for (std::size_t k = 0; k < n; k++)
-							{
-								double h = 0.0, fr = 1.0 / primes[k % 8];
-								for (unsigned q = start; q > 0; q /= primes[k % 8], fr /= primes[k % 8]) h += fr * (q % primes[k % 8]);
-								x[k] = lb[k] + h * (ub[k] - lb[k]);
-							}
-						double fx = 0.0;
-						int n_eval = 0;
-						if (gple_minimize_neldermead(f, &wrapped, static_cast<unsigned>(n), lb.data(), ub.data(), &opt, x.data(), &fx, &n_eval) != GPLE_OK) continue;
-						evals += static_cast<std::size_t>(n_eval);
-						if (fx < best_f) best_f = fx, best = x;
-					}
-					for (std::size_t i : logs) best[i] = std::exp(best[i]);
-					pv(iPES, jPES) = best;
-					num_steps.push_back(evals);
+						for (std::size_t i : logs) x[i] = std::exp(x[i]); // global_parameter_to_local, opt.cpp:197-232
+						pv(iPES, jPES) = x;
+					} // opt.cpp:549-562: a failed search keeps what it had
+					num_steps.push_back(static_cast<std::size_t>(n_eval));
 				}
 			return num_steps;
 		}

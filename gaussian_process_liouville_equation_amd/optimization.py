@@ -6,7 +6,8 @@ their results.  Every objective and constraint evaluation is one call into the H
 is computed on the host but the search itself.
 
 The reference drives NLopt 2.7 (LN_NELDERMEAD, AUGLAG_EQ over LD_SLSQP, GN_DIRECT_L; opt.h:51-55), which this image does
-not have.  The search algorithms come from SciPy instead (Nelder-Mead, SLSQP, DIRECT with locally_biased=True) and the
+not have.  The search algorithms come from SciPy (Nelder-Mead, SLSQP, DIRECT with locally_biased=True) or, searches="native", from the
+library itself (csrc/gple_opt.hip: Nelder-Mead, augmented Lagrangian, DIRECT-L behind NLopt's callback ABIs) and the
 equality-constrained stage is the augmented-Lagrangian scheme NLopt documents for AUGLAG_EQ (Birgin & Martinez 2008),
 written out below.  Iterates therefore differ from NLopt's; what is kept is the reference's control flow, tolerances,
 bounds and acceptance logic.
@@ -186,6 +187,19 @@ def _native_nelder_mead(api, fun, resident, x0, lb, ub, maxeval=None):
     return c.minimize_neldermead(lib, lambda x: fun(list(x), []), x0, lb, ub, maxeval or 0)
 
 
+def _native_direct(api, fun, resident, x0, lb, ub, maxeval=MaximumEvaluations):
+    """The library's own DIRECT-L (GN_DIRECT_L stand-in, csrc/gple_opt.hip) in the log-parameter box of the global tier: on the resident
+    objective (with a pool: one handle per context, every iteration's new rectangle centres evaluated concurrently) or calling back into `fun`."""
+    from . import _capi as c
+    lib = getattr(api, "lib", None)
+    if lib is None or not hasattr(lib, "gple_minimize_direct_l"):  # the oracle binding of the CPU tests has no searches
+        return _direct(fun, x0, lb, ub, maxeval)
+    if resident is not None and hasattr(resident, "handle"):
+        flags = [i in K._log_indices(len(x0)) for i in range(len(x0))]
+        return c.objective_minimize_direct_l(lib, [resident], x0, lb, ub, flags, maxeval)
+    return c.minimize_direct_l(lib, lambda x: fun(list(x), []), x0, lb, ub, maxeval)
+
+
 def _native_auglag_eq(fun, constraint, m, x0, lb, ub):
     """The library's augmented-Lagrangian search (gple_minimize_auglag_eq) over Python objective / constraint callbacks."""
     from . import _capi as c
@@ -258,7 +272,10 @@ class Optimization:
             try:
                 if is_global:
                     obj = lambda x, g: K.loose_function_global_wrapper(x, g, etp, api=one_api)
-                    return _direct(obj, params[e], K.local_parameter_to_global(lb), K.local_parameter_to_global(ub))
+                    glb, gub = K.local_parameter_to_global(lb), K.local_parameter_to_global(ub)
+                    if self.searches == "native":
+                        return _native_direct(one_api, obj, etp[2], params[e], glb, gub)
+                    return _direct(obj, params[e], glb, gub)
                 obj = lambda x, g: K.loose_function(x, g, etp, api=one_api)
                 if self.searches == "native":
                     return _native_nelder_mead(one_api, obj, etp[2], params[e], lb, ub, self.local_maxeval)

@@ -288,6 +288,17 @@ int gple_minimize_neldermead(gple_objective_fn f, void* data, unsigned n, const 
  * concurrently: objectives[k] are handles on the SAME data created on different contexts (one HIP stream each). */
 int gple_objective_minimize_neldermead(gple_objective* const* objectives, size_t n_objectives, size_t n, const double* lb, const double* ub,
 	const gple_opt_options* options, double* x, double* fmin, int* n_eval);
+/* GN_DIRECT_L stand-in — the global tier (opt.h:54, opt.cpp:336, 1344-1365): Gablonsky & Kelley's locally-biased DIRECT inside the finite
+ * box [lb, ub] (lb[i] == ub[i] fixes x_i; x on entry only supplies the fixed coordinates).  options->max_eval == 0: the reference's
+ * MaximumEvaluations = 100000 (opt.cpp:339); the tolerances stop the search the way NLopt's do (xtol on the rectangles an iteration
+ * divides, ftol on an iteration that improves the minimum). */
+int gple_minimize_direct_l(gple_objective_fn f, void* data, unsigned n, const double* lb, const double* ub, const gple_opt_options* options,
+	double* x, double* fmin, int* n_eval);
+/* The same search on the resident objective with all new rectangle centres of an iteration evaluated concurrently (objectives[k]: handles
+ * on the SAME data on different contexts).  is_log (nullable, n entries): coordinates that are logarithms of the parameter they stand for —
+ * loose_function_global_wrapper, opt.cpp:489-497; lb, ub and x are in those coordinates. */
+int gple_objective_minimize_direct_l(gple_objective* const* objectives, size_t n_objectives, size_t n, const double* lb, const double* ub,
+	const unsigned char* is_log, const gple_opt_options* options, double* x, double* fmin, int* n_eval);
 /* AUGLAG_EQ stand-in: minimise f subject to h(x) = 0 (m equality constraints, row-major m x n gradient) inside the box. */
 int gple_minimize_auglag_eq(gple_objective_fn f, void* fdata, gple_constraint_fn h, void* hdata, unsigned m, unsigned n, const double* lb,
 	const double* ub, const gple_opt_options* options, double* x, double* fmin, int* n_eval);

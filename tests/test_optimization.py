@@ -86,6 +86,68 @@ def test_auglag_on_a_known_problem():
     assert x == pytest.approx([1.0, 0.0, 7.0], abs=1e-3) and v == pytest.approx(2.0, abs=1e-3) and n > 0
 
 
+def _library():
+    import gaussian_process_liouville_equation_amd as pkg
+    return pkg.load_library()  # the searches are host code of the library: no GPU needed
+
+
+def test_direct_l_known_answers():
+    """gple_minimize_direct_l (the GN_DIRECT_L stand-in of the global tier, opt.h:54) on the classical test functions of the DIRECT papers
+    (Jones et al. 1993, Gablonsky & Kelley 2001), with the reference's tolerances off so that only the budget stops it: the known global
+    minima to the accuracy the papers report for these budgets, never worse than SciPy's DIRECT-L with the same budget"""
+    import ctypes as C
+    from scipy import optimize as so
+    from gaussian_process_liouville_equation_amd import _capi as c
+    lib = _library()
+
+    def run(f, lb, ub, maxeval, ftol=0.0, x_fixed=None):
+        n = len(lb)
+        cb = c.OBJECTIVE_FN(lambda nn, xp, gp, d: float(f([xp[i] for i in range(nn)])))
+        x = np.array(x_fixed if x_fixed is not None else [0.0] * n, dtype=float)
+        fv, ne, dp = C.c_double(), C.c_int(), C.POINTER(C.c_double)
+        o = c.OptOptions(1e-9, ftol, 1e-15, 0.0, 0.5, maxeval)
+        lib.gple_minimize_direct_l.argtypes = [c.OBJECTIVE_FN, C.c_void_p, C.c_uint, dp, dp, C.POINTER(c.OptOptions), dp, dp, C.POINTER(C.c_int)]
+        st = lib.gple_minimize_direct_l(cb, None, n, np.array(lb, float).ctypes.data_as(dp), np.array(ub, float).ctypes.data_as(dp), C.byref(o), x.ctypes.data_as(dp),
+                                        C.cast(C.byref(fv), dp), C.byref(ne))
+        return st, x, fv.value, ne.value
+
+    def branin(x):
+        return (x[1] - 5.1 / (4 * np.pi ** 2) * x[0] ** 2 + 5 / np.pi * x[0] - 6) ** 2 + 10 * (1 - 1 / (8 * np.pi)) * np.cos(x[0]) + 10
+
+    def sixhump(x):
+        return (4 - 2.1 * x[0] ** 2 + x[0] ** 4 / 3) * x[0] ** 2 + x[0] * x[1] + (-4 + 4 * x[1] ** 2) * x[1] ** 2
+
+    def shekel10(x):
+        A = np.array([[4, 4, 4, 4], [1, 1, 1, 1], [8, 8, 8, 8], [6, 6, 6, 6], [3, 7, 3, 7], [2, 9, 2, 9], [5, 5, 3, 3], [8, 1, 8, 1], [6, 2, 6, 2], [7, 3.6, 7, 3.6]])
+        cc = np.array([.1, .2, .2, .4, .4, .6, .3, .7, .5, .5])
+        return -np.sum(1 / (np.sum((np.asarray(x) - A) ** 2, axis=1) + cc))
+
+    def hartmann6(x):
+        A = np.array([[10, 3, 17, 3.5, 1.7, 8], [.05, 10, 17, .1, 8, 14], [3, 3.5, 1.7, 10, 17, 8], [17, 8, .05, 10, .1, 14]])
+        P = 1e-4 * np.array([[1312, 1696, 5569, 124, 8283, 5886], [2329, 4135, 8307, 3736, 1004, 9991], [2348, 1451, 3522, 2883, 3047, 6650], [4047, 8828, 8732, 5743, 1091, 381]])
+        return -np.sum(np.array([1, 1.2, 3, 3.2]) * np.exp(-np.sum(A * (np.asarray(x) - P) ** 2, axis=1)))
+
+    for f, lb, ub, fstar, budget in ((branin, [-5, 0], [10, 15], 0.3978874, 400), (sixhump, [-3, -2], [3, 2], -1.0316285, 400),
+                                     (shekel10, [0] * 4, [10] * 4, -10.5364, 1000), (hartmann6, [0] * 6, [1] * 6, -3.32237, 1500)):
+        st, x, fv, ne = run(f, lb, ub, budget)
+        assert st == 0 and budget <= ne <= budget + 40 * len(lb)  # the iteration in flight when the budget runs out is finished
+        assert abs(fv - fstar) <= 1e-4 * abs(fstar) + 1e-6, (f.__name__, fv)
+        assert fv == pytest.approx(f(list(x)), abs=1e-12) and all(l <= v <= u for v, l, u in zip(x, lb, ub))
+        ref = so.direct(f, list(zip(lb, ub)), locally_biased=True, maxfun=budget, f_min_rtol=0, vol_tol=0, len_tol=1e-12)
+        assert fv <= ref.fun + 1e-3 * abs(fstar)
+    # the reference's tolerances (opt.cpp:344-345) stop the search the way NLopt's cdirect does: at the first iteration that improves
+    # the minimum by less than ftol_rel
+    st, x, fv, ne = run(branin, [-5, 0], [10, 15], 100000, ftol=1e-5)
+    assert st == 0 and ne < 2000 and abs(fv - 0.3978874) < 1e-3
+    # a fixed coordinate (lb == ub: sigma_f and the noise in the reference's boxes) is left alone, the others are searched
+    st, x, fv, ne = run(lambda v: (v[0] - 1.0) ** 2 + (v[1] - 7.0) ** 2 + (v[2] + 0.5) ** 2, [-2, 7.0, -2], [2, 7.0, 2], 600, x_fixed=[0, 7.0, 0])
+    assert st == 0 and x[1] == 7.0 and abs(x[0] - 1.0) < 1e-3 and abs(x[2] + 0.5) < 1e-3
+    # an infinite box is refused (DIRECT needs a finite domain), NaN values count as +max (make_normal, opt.cpp:420-431)
+    assert run(branin, [-np.inf, 0], [10, 15], 100)[0] != 0
+    st, x, fv, ne = run(lambda v: float("nan") if v[0] < 0 else (v[0] - 0.25) ** 2, [-1], [1], 200)
+    assert st == 0 and abs(x[0] - 0.25) < 1e-3
+
+
 def test_optimization_driver_on_oracle(oracle):
     _check(*_run(oracle, 60), oracle)
 
@@ -136,6 +198,38 @@ def test_optimization_with_the_native_searches(gpu):
     ks = K.TrainingKernels(p, K.construct_training_sets(density), False, True, False, api=gpu)
     assert abs(ks.calculate_population() - 1.0) < 2 * O.AverageTolerance
     assert abs(ks.calculate_purity() - 1.0) < 2 * O.AverageTolerance
+
+
+@pytest.mark.gpu
+def test_direct_l_on_the_resident_objective(gpu):
+    """the global tier's search (opt.cpp:1344-1365) inside the library: DIRECT-L in the log-parameter box on the resident objective; with
+    three handles on three contexts every iteration's new rectangle centres are evaluated concurrently and the result is the sequential one;
+    the Python callback form (gple_minimize_direct_l over loose_function_global_wrapper) walks the same rectangles"""
+    import gaussian_process_liouville_equation_amd as pkg
+    from gaussian_process_liouville_equation_amd import _capi as c
+    from tests import parity
+    X, y, _ = parity.synthetic_real(300, 1, 78)
+    rng = np.random.default_rng(4)
+    Xe = X[np.arange(900) % 300] + rng.normal(0, 0.5, size=(900, 2))
+    ye = np.exp(-0.5 * (((Xe[:, 0] + 10.0) / 0.7086) ** 2 + ((Xe[:, 1] - 14.112) / 0.7056) ** 2)) / (2 * np.pi * 0.7086 * 0.7056)
+    apis = [gpu, pkg.open_api(0), pkg.open_api(0)]
+    objs = [a.objective(X, y.astype(complex), Xe, ye.astype(complex)) for a in apis]
+    lb, ub = [1.0, 0.05, 0.05, 1e-2], [1.0, 6.0, 6.0, 1e-2]
+    flags = [i in K._log_indices(4) for i in range(4)]
+    glb, gub, x0 = K.local_parameter_to_global(lb), K.local_parameter_to_global(ub), K.local_parameter_to_global([1.0, 1.0, 1.0, 1e-2])
+    x1, f1, n1 = c.objective_minimize_direct_l(gpu.lib, objs[:1], x0, glb, gub, flags, 600)
+    x3, f3, n3 = c.objective_minimize_direct_l(gpu.lib, objs, x0, glb, gub, flags, 600)
+    assert x1 == x3 and f1 == f3 and n1 == n3 and n1 > 20
+    etp = ((X, y.astype(complex)), (Xe, ye.astype(complex)), objs[0])
+    xc, fc, nc = c.minimize_direct_l(gpu.lib, lambda x: K.loose_function_global_wrapper(list(x), [], etp, api=gpu), x0, glb, gub, 600)
+    assert xc == x1 and fc == f1 and nc == n1
+    best = K.global_parameter_to_local(x1)
+    assert f1 <= objs[0]([1.0, 1.0, 1.0, 1e-2], want_grad=False)[0] and best[0] == 1.0 and abs(best[3] - 1e-2) < 1e-15
+    assert 0.3 < best[1] < 1.6 and 0.3 < best[2] < 1.6  # the packet's widths are 0.71: the basin every local search of this case ends in
+    for o in objs:
+        o.release()
+    for a in apis[1:]:
+        a.close()
 
 
 @pytest.mark.gpu
