@@ -265,6 +265,48 @@ namespace gple
 		}
 	} // namespace
 
+	namespace
+	{
+		// one wave per column i: three column dots over the Np rows of M_a
+		__global__ void __launch_bounds__(256) cderiv_diag_kernel(const double* __restrict__ M, long ldm, int roff, const double* __restrict__ E,
+			const double* __restrict__ F, long lde, int Np, int n, double alpha, double* __restrict__ out_diag, double* __restrict__ out_off)
+		{
+			const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+			if (i >= n) return;
+			const double* __restrict__ mi = M + roff + static_cast<long>(i) * ldm;
+			const double* __restrict__ ei = E + static_cast<long>(i) * lde;
+			const double* __restrict__ fi = F + static_cast<long>(i) * lde;
+			double d = 0.0, o = 0.0;
+			if (i < Np)
+			{
+				const double* __restrict__ mp = M + roff + static_cast<long>(Np + i) * ldm;
+				const double* __restrict__ ep = E + static_cast<long>(Np + i) * lde;
+				const double* __restrict__ fp = F + static_cast<long>(Np + i) * lde;
+				for (int j = lane; j < Np; j += 64)
+				{
+					const double m = mi[j], f = fi[j];
+					d = fma(m, ei[j] + 2.0 * f, d);
+					o = fma(m, ep[j] + fp[j], o);
+					o = fma(mp[j], f, o);
+				}
+			}
+			else
+				for (int j = lane; j < Np; j += 64) d = fma(mi[j], ei[j] + 2.0 * fi[j], d);
+#pragma unroll
+			for (int sft = 32; sft > 0; sft >>= 1) d += __shfl_xor(d, sft), o += __shfl_xor(o, sft);
+			if (lane == 0)
+			{
+				out_diag[i] = alpha * d;
+				if (i < Np) out_off[i] = alpha * o;
+			}
+		}
+	} // namespace
+	hipError_t launch_cderiv_diag(hipStream_t s, const double* M, long ldm, int roff, const double* E, const double* F, long lde, int Np, int n, double alpha,
+		double* out_diag, double* out_off)
+	{
+		hipLaunchKernelGGL(cderiv_diag_kernel, dim3((n + 3) / 4), dim3(256), 0, s, M, ldm, roff, E, F, lde, Np, n, alpha, out_diag, out_off);
+		return hipGetLastError();
+	}
 	hipError_t launch_typed_deriv_gram(hipStream_t s, const double* Xt, int N, int Np, int n, DSpecSet spec, double* D)
 	{
 		hipLaunchKernelGGL(typed_deriv_gram_kernel, dim3(n / 64, n / 16), dim3(256), 0, s, Xt, N, Np, n, spec, D);

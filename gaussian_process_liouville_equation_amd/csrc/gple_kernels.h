@@ -62,6 +62,14 @@ namespace gple
 	};
 	// dC (n x n, padded with zeros) of the typed training set
 	hipError_t launch_typed_deriv_gram(hipStream_t s, const double* Xt, int N, int Np, int n, DSpecSet spec, double* D);
+	// Diagonals of M dC M for a dC with ONE zero diagonal block (every sub-kernel parameter of the complex GP, build_dspecs): with the
+	// non-zero diagonal block A and the off-diagonal block B of dC, E = A M_a and F = B M_b (Np x n each; M_a = the rows of M on A's side,
+	// M_b the others; roff = first row of M_a) give
+	//   diag(M dC M)_i          = sum_j M_a(j, i) (E + 2 F)(j, i)                                   i < n
+	//   (M dC M)(i, Np + i)      = sum_j M_a(j, i) (E + F)(j, Np + i) + M_a(j, Np + i) F(j, i)        i < Np
+	// out_diag (n) and out_off (Np) receive alpha times these: half the flops of the full product dC M.
+	hipError_t launch_cderiv_diag(hipStream_t s, const double* M, long ldm, int roff, const double* E, const double* F, long lde, int Np, int n, double alpha,
+		double* out_diag, double* out_off);
 	// out[ip] (ip = 0..7) = TrainingComplexKernel::ErrorDerivatives (complex_kernel.cpp:444-474) from the embedded quantities:
 	// w (weights, n), wd (diag M, n), wx (diag of the Re-Im block, Np) and their derivatives dw (8 x n), dwd (8 x n), dwx (8 x Np)
 	hipError_t launch_complex_deriv_sums(hipStream_t s, const double* w, const double* wd, const double* wx, const double* dw, const double* dwd,
