@@ -98,8 +98,19 @@ namespace gple
 			const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
 			// K_LE_M: the k-range of a tile grows with its row block; workgroups are dispatched in blockIdx.x order, so the row
 			// blocks are walked from the bottom up — the longest tiles start first and the short ones fill the tail
-			const int bx = g.krange == K_LE_M ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
-			const int m0 = bx * BM, n0 = blockIdx.y * BN;
+			int bx = g.krange == K_LE_M ? gridDim.x - 1 - blockIdx.x : blockIdx.x, by = blockIdx.y;
+			// Dense products: workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), each XCD with its own 4 MB L2.
+			// In plain order the ~64 workgroups resident on one XCD are every 8th row tile of a few columns: 64 operand panels for 64
+			// tiles, and the n = 8192 derivative GEMM fetched 15 x its algorithmic bytes from HBM (profiles/r03_traffic.json, C4opt_only1
+			// v1).  Here XCD x works through its own strip of N-tiles in row-major order: the resident workgroups form a block of
+			// (64 / strip width) x (strip width) tiles that moves through k together.  Placement is a speed matter only (the tile -> result
+			// map is the same), and dispatch order is not promised: if it ever changes the kernel is merely back to the old traffic.
+			if (g.krange == K_FULL && !g.lower_only && gridDim.y % 8 == 0 && gridDim.z == 1)
+			{
+				const int L = blockIdx.x + gridDim.x * blockIdx.y, sw = gridDim.y / 8, j = L >> 3;
+				by = (L & 7) * sw + j % sw, bx = j / sw;
+			}
+			const int m0 = bx * BM, n0 = by * BN;
 			if (g.lower_only && n0 >= m0 + BM) return;
 			int kb = 0, ke = g.K;
 			if (g.krange == K_GE_N) kb = n0;

@@ -55,11 +55,17 @@ if kind in ("real", "complex") and dom.startswith("rownorm"):
     entry["note"] = ("K* chunk re-read once per 256-column tile of T it meets, M_chunk * n * 8 * (ntiles + 1) / 2, + the lower triangle of T once "
                      "(the per-workgroup re-reads of T are served by L2 / MALL)")
 elif kind == "opt":
-    n = 2 * N if tag.endswith("only1") else N
-    entry["launch"] = f"dK * K^-1 of one length parameter, n = {n}"
-    entry["algorithmic_bytes_per_launch"] = int(3 * n * n * 8)
-    entry["algorithmic_flops_per_launch"] = 2.0 * n ** 3
-    entry["note"] = "dense n x n x n product: both operands read once, the result written once (tile re-reads are served by L2 / MALL)"
+    if tag.endswith("only1"):  # the complex element: two N x 2N x N block products per sub-kernel parameter (csrc/gple_capi.hip, complex_fit_derivatives)
+        entry["launch"] = f"E = A M_a or F = B M_b of one sub-kernel parameter: {N} x {2 * N} x {N}"
+        entry["algorithmic_bytes_per_launch"] = int(5 * N * N * 8)
+        entry["algorithmic_flops_per_launch"] = 4.0 * N ** 3
+        entry["note"] = ("block product N x 2N x N: A (N x N) and M's half (2N x N) read once, the result (N x 2N) written once; the XCD-aware tile order "
+                         "leaves one 8 x 8-tile block of operand panels per XCD at a time: 16 panels of 4 MB per 64 tiles = 2.0 GB + 0.27 GB written expected")
+    else:
+        entry["launch"] = f"dK * K^-1 of one length parameter, n = {N}"
+        entry["algorithmic_bytes_per_launch"] = int(3 * N * N * 8)
+        entry["algorithmic_flops_per_launch"] = 2.0 * N ** 3
+        entry["note"] = "dense n x n x n product: both operands read once, the result written once (tile re-reads are served by L2 / MALL)"
 if entry.get("algorithmic_bytes_per_launch"):
     entry["traffic_over_algorithmic"] = round(entry["hbm_bytes_per_launch"] / entry["algorithmic_bytes_per_launch"], 3)
 if entry.get("algorithmic_flops_per_launch") and entry.get("rocprof_average_ms"):
