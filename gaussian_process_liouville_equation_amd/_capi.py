@@ -204,7 +204,7 @@ GPLE_SYMBOLS = [
     "real_gram", "complex_gram", "cutoff_factor", "predict_batch", "shard_bounds", "set_allgather_function", "real_predict_sharded", "complex_predict_sharded", "real_predict_dealt", "complex_predict_dealt", "deal_share",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
-    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "minimize_neldermead", "objective_minimize_neldermead", "minimize_direct_l", "objective_minimize_direct_l", "minimize_auglag_eq", "pes_adiabatic", "evolve", "markov_chain", "markov_chain_trace", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
+    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "minimize_neldermead", "objective_minimize_neldermead", "minimize_direct_l", "objective_minimize_direct_l", "minimize_auglag_eq", "pes_adiabatic", "evolve", "evolve_n", "pes_adiabatic_n", "markov_chain", "markov_chain_trace", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
 ]
 
 
@@ -457,6 +457,39 @@ class Api:
             pts[k].r, pts[k].rho, pts[k].n = _ptr(rs[k]), _ptr(rhos[k].view(np.float64)), len(rs[k])
         self.lib.gple_evolve.argtypes = [C.c_void_p, C.POINTER(Element), C.c_int, C.c_double, C.c_double, C.POINTER(Points), C.c_uint]
         self._check(self.lib.gple_evolve(self.ctx, self._elements(fits), int(model), float(mass), float(dt), pts, EVOLVE_NEW_POINTS if new_points else 0))
+        return {e: (rs[k], rhos[k]) for k, e in enumerate(order)}
+
+    def pes_adiabatic_n(self, num_pes, model, x):
+        """N-level adiabatic quantities at positions x: (E (M, N), F (M, N, N) symmetric, NAC (M, N, N) antisymmetric, NAC[j, k] = F[j, k] / (E_j - E_k))"""
+        x = _f64(x)
+        ne = num_pes * (num_pes + 1) // 2
+        w = num_pes + 2 * ne
+        out = np.empty(w * len(x))
+        self.lib.gple_pes_adiabatic_n.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_size_t, C.c_uint, _dp]
+        self._check(self.lib.gple_pes_adiabatic_n(self.ctx, int(num_pes), int(model), _ptr(x), len(x), 0, _ptr(out)))
+        out = out.reshape(-1, w)
+        E, F, NAC = out[:, :num_pes].copy(), np.zeros((len(x), num_pes, num_pes)), np.zeros((len(x), num_pes, num_pes))
+        e = 0
+        for k in range(num_pes):
+            for l in range(k + 1):
+                F[:, k, l] = F[:, l, k] = out[:, num_pes + e]
+                NAC[:, k, l], NAC[:, l, k] = out[:, num_pes + ne + e], -out[:, num_pes + ne + e]
+                e += 1
+        return E, F, NAC
+
+    def evolve_n(self, num_pes, fits, model, mass, dt, density, new_points=False):
+        """gple_evolve_n: one tick for an N-level system; fits and density in the packing order (0,0), (1,0), (1,1), (2,0), ...;
+        density = {(i, j): (r (n, 2), rho (n,))} -> the same structure one tick later"""
+        order = [(i, j) for i in range(num_pes) for j in range(i + 1)]
+        empty = (np.zeros((0, 2)), np.zeros(0, dtype=complex))
+        rs = [np.ascontiguousarray(np.asarray(density.get(e, empty)[0], dtype=np.float64).reshape(-1, 2)).copy() for e in order]
+        rhos = [np.ascontiguousarray(np.asarray(density.get(e, empty)[1], dtype=np.complex128)).copy() for e in order]
+        pts = (Points * len(order))()
+        for k in range(len(order)):
+            pts[k].r, pts[k].rho, pts[k].n = _ptr(rs[k]), _ptr(rhos[k].view(np.float64)), len(rs[k])
+        self.lib.gple_evolve_n.argtypes = [C.c_void_p, C.c_int, C.POINTER(Element), C.c_int, C.c_double, C.c_double, C.POINTER(Points), C.c_uint]
+        self._check(self.lib.gple_evolve_n(self.ctx, int(num_pes), self._elements(fits), int(model), float(mass), float(dt), pts,
+                                           EVOLVE_NEW_POINTS if new_points else 0))
         return {e: (rs[k], rhos[k]) for k, e in enumerate(order)}
 
     def markov_chain(self, fit, num_steps, max_displacement, seed, r, want_chain=False):

@@ -1994,6 +1994,103 @@ extern "C"
 		return GPLE_OK;
 	}
 
+	/* N-level form of gple_evolve / gple_pes_adiabatic (gple_evolve_n.hip): num_pes = 2 or 3, NE = num_pes (num_pes + 1) / 2 elements in the
+	 * packing order (0,0), (1,0), (1,1), (2,0), (2,1), (2,2) */
+	int gple_pes_adiabatic_n(gple_ctx* ctx, int num_pes, int model, const double* x, size_t M, unsigned flags, double* out)
+	{
+		if (!ctx || (num_pes != 2 && num_pes != 3) || model < 0 || model > (num_pes == 3 ? 3 : 2) || (M && (!x || !out)) || M > (1u << 28)) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		if (M == 0) return GPLE_OK;
+		const bool dev = flags & GPLE_IO_DEVICE;
+		const size_t width = static_cast<size_t>(num_pes) + 2 * static_cast<size_t>(num_pes * (num_pes + 1) / 2);
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		Scratch xd(ctx), od(ctx);
+		const double* xin = x;
+		double* o = out;
+		if (!dev)
+		{
+			GPLE_HIP(ctx, xd.get(M));
+			GPLE_HIP(ctx, od.get(width * M));
+			GPLE_HIP(ctx, copy_in(st, xd.p, x, M, false));
+			xin = xd.p, o = od.p;
+		}
+		GPLE_HIP(ctx, launch_pes_n(st, num_pes, xin, static_cast<int>(M), model, o));
+		if (!dev)
+		{
+			GPLE_HIP(ctx, copy_out(st, out, od.p, width * M, false));
+			GPLE_HIP(ctx, hipStreamSynchronize(st));
+		}
+		return GPLE_OK;
+	}
+
+	int gple_evolve_n(gple_ctx* ctx, int num_pes, const gple_element* elements, int pes_model, double mass, double dt, gple_points* density, unsigned flags)
+	{
+		if (!ctx || !elements || !density || (num_pes != 2 && num_pes != 3) || pes_model < 0 || pes_model > (num_pes == 3 ? 3 : 2) || !(mass > 0.0))
+			return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(ctx);
+		const int NE = num_pes * (num_pes + 1) / 2;
+		int n[6] = {0, 0, 0, 0, 0, 0}, off[6];
+		bool diagonal[6];
+		size_t total = 0;
+		for (int i = 0, e = 0; i < num_pes; ++i)
+			for (int j = 0; j <= i; ++j, ++e) diagonal[e] = i == j;
+		for (int e = 0; e < NE; ++e)
+		{
+			if (density[e].n > (1u << 26) || (density[e].n && (!density[e].r || !density[e].rho))) return GPLE_ERR_BAD_ARG;
+			if (elements[e].real && elements[e].cplx) return GPLE_ERR_BAD_ARG;
+			if ((elements[e].real && !diagonal[e]) || (elements[e].cplx && diagonal[e])) return GPLE_ERR_BAD_ARG; // real GPs on the diagonal, complex ones off it
+			n[e] = static_cast<int>(density[e].n), off[e] = static_cast<int>(total);
+			total += density[e].n;
+		}
+		if (total == 0) return GPLE_OK;
+		const bool dev = flags & GPLE_IO_DEVICE;
+		const int new_points = (flags & GPLE_EVOLVE_NEW_POINTS) ? 1 : 0;
+		long qlen[6];
+		evolve_layout_n(num_pes, n, qlen);
+		hipStream_t st = ctx->stream;
+		Scratch r_old(ctx), rho_old(ctx), r_new(ctx), rho_new(ctx);
+		std::vector<std::unique_ptr<Scratch>> q, pr;
+		double* qp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+		{
+			std::lock_guard<std::mutex> lk(ctx->call_mu);
+			GPLE_HIP(ctx, hipSetDevice(ctx->device));
+			GPLE_HIP(ctx, r_old.get(2 * total));
+			GPLE_HIP(ctx, rho_old.get(2 * total));
+			GPLE_HIP(ctx, r_new.get(2 * total));
+			GPLE_HIP(ctx, rho_new.get(2 * total));
+			for (int e = 0; e < NE; ++e)
+			{
+				q.emplace_back(new Scratch(ctx)), pr.emplace_back(new Scratch(ctx));
+				GPLE_HIP(ctx, q[e]->get(2 * static_cast<size_t>(qlen[e]) + 2));
+				GPLE_HIP(ctx, pr[e]->get(2 * static_cast<size_t>(qlen[e]) + 2));
+				qp[e] = q[e]->p;
+				GPLE_HIP(ctx, copy_in(st, r_old.p + 2 * off[e], density[e].r, 2 * density[e].n, dev));
+				GPLE_HIP(ctx, copy_in(st, rho_old.p + 2 * off[e], density[e].rho, 2 * density[e].n, dev));
+			}
+			GPLE_HIP(ctx, launch_evolve_prepare_n(st, num_pes, r_old.p, n, mass, dt, pes_model, r_new.p, qp, new_points));
+		}
+		// one batched predict per density-matrix element over everything that was back-propagated into it
+		const double* pred[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+		for (int e = 0; e < NE; ++e)
+		{
+			if (qlen[e] == 0 || (!elements[e].real && !elements[e].cplx)) continue;
+			GPLE_TRY(predict_element_cutoff(ctx, elements[e], q[e]->p, static_cast<size_t>(qlen[e]), pr[e]->p));
+			pred[e] = pr[e]->p;
+		}
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		GPLE_HIP(ctx, launch_evolve_combine_n(st, num_pes, r_new.p, rho_old.p, n, mass, dt, pes_model, pred, rho_new.p, new_points));
+		for (int e = 0; e < NE; ++e)
+		{
+			GPLE_HIP(ctx, copy_out(st, density[e].r, r_new.p + 2 * off[e], 2 * density[e].n, dev));
+			GPLE_HIP(ctx, copy_out(st, density[e].rho, rho_new.p + 2 * off[e], 2 * density[e].n, dev));
+		}
+		GPLE_HIP(ctx, hipStreamSynchronize(st)); // the scratch lists go back to the pool when this returns
+		return GPLE_OK;
+	}
+
 	static int markov_chain_impl(gple_ctx* ctx, const gple_element* element, size_t num_steps, double max_displacement, unsigned long long seed, double* r,
 		size_t n, double* accept_ratio, double* chain)
 	{

@@ -174,4 +174,13 @@ namespace gple
 	// complex finish: rows [0,M) real part, rows [m_split, m_split+M) imaginary part
 	hipError_t launch_predict_finish_complex(hipStream_t s, const double* q, const double* mu, int M, int m_split, double self,
 		const double* s_dev, const double* labels, double* mean, double* var, double* cut, double* err_out);
+	// ---- N-level step loop (gple_evolve_n.hip): NumPES = 2 or 3, elements in the packing order (0,0), (1,0), (1,1), (2,0), ... ----
+	// adiabatic quantities: out[(NP + 2 NE) i + ...] = E (NP) | F lower-packed (NE) | NAC lower-packed (NE)
+	hipError_t launch_pes_n(hipStream_t s, int num_pes, const double* x, int M, int model, double* out);
+	// rows of every element's query list: NE branches of every point of every element
+	void evolve_layout_n(int num_pes, const int* n, long* qlen);
+	hipError_t launch_evolve_prepare_n(hipStream_t s, int num_pes, const double* r, const int* n, double mass, double dt, int model, double* r_new,
+		double* const* q, int new_points);
+	hipError_t launch_evolve_combine_n(hipStream_t s, int num_pes, const double* r_new, const double* rho_old, const int* n, double mass, double dt, int model,
+		const double* const* pred, double* rho_new, int new_points);
 } // namespace gple

@@ -21,17 +21,22 @@ import numpy as np
 from . import kernels as K
 
 SAC, DAC, ECR = 0, 1, 2  # pes.h:27-32; TestModel defaults to DAC (pes.h:38-41)
+TSAC = 3  # three-state avoided crossings: this library's three-level model (num_pes = 3 only; include/gple.h, gple_evolve_n)
 _ORDER = [(0, 0), (1, 0), (1, 1)]
 
 
+def element_order(num_pes):
+    return [(i, j) for i in range(num_pes) for j in range(i + 1)]
+
+
 def _fits(all_kernels):
-    return [None if all_kernels(i, j) is None else all_kernels(i, j)._fit for (i, j) in _ORDER]
+    return [None if all_kernels(i, j) is None else all_kernels(i, j)._fit for (i, j) in element_order(all_kernels.num_pes)]
 
 
 def _api(all_kernels, api):
     if api is not None:
         return api
-    for (i, j) in _ORDER:
+    for (i, j) in element_order(getattr(all_kernels, "num_pes", 2)):
         if all_kernels(i, j) is not None:
             return all_kernels(i, j)._api
     return K.default_api()
@@ -45,7 +50,8 @@ def _points(density):
 def evolve(density, mass, dt, all_kernels, model=DAC, api=None):
     """evolve.cpp:377-423: every selected point of every element one time step further, with its density rebuilt by
     back-propagation against the current fit.  density: {(iPES, jPES): (r (n, 2), rho (n,) complex)}; returns the same."""
-    assert all_kernels.num_pes == 2, "the reference instantiates the two-level system only (evolve.cpp:367-371)"
+    if all_kernels.num_pes != 2:  # beyond the reference (evolve.cpp:367-371 asserts): the N-level back-propagation of gple_evolve_n (DESIGN.md §10)
+        return _api(all_kernels, api).evolve_n(all_kernels.num_pes, _fits(all_kernels), model, float(np.ravel(mass)[0]), dt, density)
     return _api(all_kernels, api).evolve(_fits(all_kernels), model, float(np.ravel(mass)[0]), dt, _points(density))
 
 
@@ -270,10 +276,11 @@ def tick(density, extra_points, ParameterVectors, mass, dt, all_kernels, model=D
     """main.cpp:143-176 without the re-optimisation branches: evolve the density and the extra points against the current
     kernels, then refit the kernels on the evolved density (TrainingKernels(params, density), predict.cpp:390-393)."""
     api = _api(all_kernels, api)
+    num_pes = all_kernels.num_pes
     density = evolve(density, mass, dt, all_kernels, model, api)
     extra_points = evolve(extra_points, mass, dt, all_kernels, model, api)
-    sets = K.construct_training_sets({e: v for e, v in density.items() if len(v[0])}, 2)
-    new_kernels = K.TrainingKernels(ParameterVectors, sets, True, True, False, api=api, num_pes=2)
+    sets = K.construct_training_sets({e: v for e, v in density.items() if len(v[0])}, num_pes)
+    new_kernels = K.TrainingKernels(ParameterVectors, sets, True, True, False, api=api, num_pes=num_pes)
     return density, extra_points, new_kernels
 
 

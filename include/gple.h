@@ -333,6 +333,21 @@ typedef struct gple_points
 int gple_evolve(gple_ctx* ctx, const gple_element elements[3], int pes_model, double mass, double dt, gple_points density[3],
 	unsigned flags);
 
+/* The same for N-level systems — SURVEY.md §8f N3 "extend non_adiabatic_evolve_predict beyond NumPES == 2" (the reference asserts there,
+ * evolve.cpp:367-371); num_pes = 2 or 3, elements and density hold NE = num_pes (num_pes + 1) / 2 entries in the reference's packing order
+ * (0,0), (1,0), (1,1), (2,0), (2,1), (2,2): real fits on the diagonal, complex ones off it.  The back-propagation is the N-level form of the
+ * operator splitting the two-level code implements: NE momentum branches (the eigen-pairs of the off-diagonal force matrix)
+ * x NE source elements of predicted densities per point, one batch per element; at num_pes = 2 it reproduces gple_evolve to rounding.
+ * pes_model 0-2: pes.cpp's diabatic_potential as it compiles for num_pes levels (Tully's two surfaces; at three levels plus the uncoupled
+ * third diabat at V = 0 that the unfilled matrix entries give); 3 (num_pes = 3 only): a three-state avoided-crossing model of this library,
+ * V00 = A tanh(B x), V11 = 0, V22 = -A tanh(B x), V01 = V12 = C sech(D x) with A = 0.02, B = 0.8, C = 0.005, D = 0.5 — the reference has no
+ * genuinely three-level model.  Adiabatic states: ascending energy, last non-zero component of every eigenvector positive. */
+int gple_evolve_n(gple_ctx* ctx, int num_pes, const gple_element* elements, int pes_model, double mass, double dt, gple_points* density,
+	unsigned flags);
+/* adiabatic_potential / adiabatic_force / adiabatic_coupling (pes.cpp:98-155) for num_pes levels at M positions:
+ * out[(num_pes + 2 NE) i + ...] = E (num_pes, ascending) | F lower-packed (NE) | NAC lower-packed (NE; NAC(j, k) = F(j, k) / (E_j - E_k), j > k). */
+int gple_pes_adiabatic_n(gple_ctx* ctx, int num_pes, int model, const double* x, size_t M, unsigned flags, double* out);
+
 /* generate_markov_chain (mc.cpp:118-165) for n walkers at once on the fitted distribution |cut-off prediction| of `element`:
  * num_steps Metropolis steps with uniform displacements in [-max_displacement, max_displacement) per dimension; r (2n) holds
  * the start points and receives the last points, accept_ratio (nullable, n) the accepted fraction per walker.  Random numbers:

@@ -129,3 +129,103 @@ def test_extra_points_and_host_chain():
     # the chain samples |rho|: after many steps the walkers' spread is that of the density
     last, _ = chain(1500, 0.8, np.tile([[-10.0, 14.112]], (400, 1)))
     assert np.all(np.abs(last.std(axis=0) / sig - 1.0) < 0.2)
+
+
+# ---- N-level step loop (oracle/evolve_oracle_n.py): the derived generalisation of evolve.cpp:184-372 ------------------------------------------
+
+def _smooth_distribution(pts, i, j):
+    x, p = pts[:, 0], pts[:, 1]
+    g = np.exp(-0.5 * (((x + 1.5) / 0.8) ** 2 + ((p - 14.0) / 0.9) ** 2))
+    if i == j:
+        return g * (0.6, 0.3, 0.1)[i] + 0j
+    return g * 0.2 * np.exp(0.4j * (x + 1.5) + 0.1j * (i + j))
+
+
+@pytest.mark.parametrize("model", [E.SAC, E.DAC, E.ECR])
+def test_n_level_oracle_reduces_to_the_two_level_reference_code(model):
+    """The projector form of the back-propagation (P_a rho P_b shifted by (lambda_a + lambda_b) / 2; rho <- O rho O^T with O = exp(-v D t))
+    at N = 2 IS the reference's three-branch code (evolve.cpp:184-372, restated in oracle/evolve_oracle.py): same values to rounding for every
+    element, with the exact density on the zero-shift branch and without it, and the same adiabatic quantities."""
+    from oracle import evolve_oracle_n as EN
+    rng = np.random.default_rng(model)
+    r = rng.normal([-1.5, 14.0], [0.8, 0.9], size=(60, 2))
+    En, _, Fn, NACn = EN.adiabatic(r[:, 0], model, 2)
+    e0, e1 = E.adiabatic_potential(r[:, 0], model)
+    f00, f10, f11 = E.adiabatic_force(r[:, 0], model)
+    assert np.abs(En[:, 0] - e0).max() <= 1e-16 and np.abs(En[:, 1] - e1).max() <= 1e-16
+    assert max(np.abs(Fn[:, 0, 0] - f00).max(), np.abs(Fn[:, 1, 0] - f10).max(), np.abs(Fn[:, 1, 1] - f11).max()) <= 1e-14
+    assert np.abs(NACn[:, 0, 1] - E.adiabatic_coupling_01(r[:, 0], model)).max() <= 1e-12 * np.abs(NACn).max()
+    for (i, j) in [(0, 0), (1, 0), (1, 1)]:
+        rho = _smooth_distribution(r, i, j) * 1.01
+        for dens in (rho, None):
+            a = E.non_adiabatic_evolve_predict(r, dens, 2000.0, 1.0, _smooth_distribution, i, j, model)
+            b = EN.non_adiabatic_evolve_predict(r, dens, 2000.0, 1.0, _smooth_distribution, i, j, model, 2)
+            assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max(), (i, j)
+    dens = {e: (r, _smooth_distribution(r, *e)) for e in [(0, 0), (1, 0), (1, 1)]}
+    a, b = E.evolve(dens, 2000.0, 1.0, _smooth_distribution, model), EN.evolve(dens, 2000.0, 1.0, _smooth_distribution, model, 2)
+    for e in dens:
+        assert np.abs(a[e][0] - b[e][0]).max() <= 1e-13 * np.abs(a[e][0]).max() and np.abs(a[e][1] - b[e][1]).max() <= 1e-13 * np.abs(a[e][1]).max()
+
+
+@pytest.mark.parametrize("model", [E.SAC, E.DAC, E.ECR])
+def test_three_levels_with_a_spectator_reproduce_the_two_level_block(model):
+    """pes.cpp compiled for NumPES = 3 leaves the third diabat uncoupled at V = 0: the two Tully states evolve among themselves exactly as in the
+    two-level code, the spectator's population moves on its own flat surface, and its coherences only turn with the 0-1 rotation"""
+    from oracle import evolve_oracle_n as EN
+    rng = np.random.default_rng(10 + model)
+    r = rng.normal([-1.5, 14.0], [0.8, 0.9], size=(40, 2))
+    E3 = EN.adiabatic(r[:, 0], model, 3)[0]
+    E2 = EN.adiabatic(r[:, 0], model, 2)[0]
+    spect = int(np.argmin(np.abs(E3[0])))            # the adiabatic index the spectator (E = 0 exactly) has at these positions
+    assert np.all(E3[:, spect] == 0.0)
+    tully = [k for k in range(3) if k != spect]
+    assert np.abs(E3[:, tully] - E2).max() <= 1e-16
+    emb = {0: tully[0], 1: tully[1]}
+
+    def dist3(pts, i, j):  # the two-level distribution on the Tully block, nothing on the spectator
+        inv = {v: k for k, v in emb.items()}
+        if i in inv and j in inv:
+            a, b = inv[i], inv[j]
+            v = _smooth_distribution(pts, max(a, b), min(a, b))
+            return v if a >= b else np.conj(v)
+        return np.zeros(len(pts), dtype=complex)
+
+    for (i, j) in [(0, 0), (1, 0), (1, 1)]:
+        a = E.non_adiabatic_evolve_predict(r, None, 2000.0, 1.0, _smooth_distribution, i, j, model)
+        k, l = emb[i], emb[j]
+        b = EN.non_adiabatic_evolve_predict(r, None, 2000.0, 1.0, dist3, max(k, l), min(k, l), model, 3)
+        if k < l:
+            b = np.conj(b)
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max(), (i, j)
+    # nothing leaks onto the spectator
+    assert np.abs(EN.non_adiabatic_evolve_predict(r, None, 2000.0, 1.0, dist3, spect, spect, model, 3)).max() <= 1e-18
+
+
+def test_three_state_model_invariants():
+    """TSAC (the library's own three-level model): avoided crossings of sqrt(2) C, Hellmann-Feynman forces, NAC from the force matrix,
+    continuous eigenvector signs; the back-propagation maps a multiple of the identity onto itself (unitary mixing + translations), keeps
+    Hermitian structure (a real symmetric, momentum-independent density stays real symmetric) and is exact for a flat density"""
+    from oracle import evolve_oracle_n as EN
+    x = np.linspace(-12, 12, 4801)
+    En, Cn, Fn, NACn = EN.adiabatic(x, EN.TSAC, 3)
+    assert abs((En[:, 1] - En[:, 0]).min() - np.sqrt(2) * EN.TSAC_C) < 1e-6 and abs((En[:, 2] - En[:, 1]).min() - np.sqrt(2) * EN.TSAC_C) < 1e-6
+    h = 1e-6
+    dE = (EN.adiabatic(x + h, EN.TSAC, 3)[0] - EN.adiabatic(x - h, EN.TSAC, 3)[0]) / (2 * h)
+    assert np.abs(np.einsum("mkk->mk", Fn) + dE).max() <= 1e-8
+    assert np.abs(np.diff(Cn, axis=0)).max() < 0.02              # no sign flips along x
+    dC = (EN.adiabatic(x + h, EN.TSAC, 3)[1] - EN.adiabatic(x - h, EN.TSAC, 3)[1]) / (2 * h)
+    d_num = np.einsum("mik,mil->mkl", Cn, dC)                      # <k | d/dx | l>
+    assert np.abs(d_num - NACn).max() <= 1e-6 * np.abs(NACn).max()  # pes.cpp:137-155's F / (E_j - E_k) is the derivative coupling
+    rng = np.random.default_rng(3)
+    r = rng.normal([0.3, 14.0], [0.8, 0.9], size=(25, 2))
+    ident = lambda pts, i, j: (np.ones(len(pts)) if i == j else np.zeros(len(pts))) + 0j
+    for (i, j) in EN.elements(3):
+        v = EN.non_adiabatic_evolve_predict(r, None, 2000.0, 1.0, ident, i, j, EN.TSAC, 3)
+        assert np.abs(v - (1.0 if i == j else 0.0)).max() <= 1e-13
+    sym = np.array([[0.5, 0.1, -0.05], [0.1, 0.3, 0.07], [-0.05, 0.07, 0.2]])
+    flat = lambda pts, i, j: np.full(len(pts), sym[i, j], dtype=complex)
+    # a constant real symmetric matrix: the result stays Hermitian (real diagonal); its trace moves only by the branch-dependent phases
+    # (E_k - E_l) t / 2 of the off-diagonal entries, second order in the step — the same holds for the two-level code
+    vals = {e: EN.non_adiabatic_evolve_predict(r, None, 2000.0, 1.0, flat, e[0], e[1], EN.TSAC, 3) for e in EN.elements(3)}
+    assert np.abs(sum(vals[(k, k)] for k in range(3)) - np.trace(sym)).max() <= 1e-4
+    assert max(np.abs(vals[(k, k)].imag).max() for k in range(3)) <= 1e-15
