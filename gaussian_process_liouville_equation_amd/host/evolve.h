@@ -94,23 +94,30 @@ namespace gple_host
 				}
 		}
 	};
+	/// the device tick for the system the translation unit is compiled for: two levels = the reference's own three-branch back-propagation
+	/// (gple_evolve); three levels = its N-level form (gple_evolve_n), where the reference asserts (evolve.cpp:367-371)
+	inline int tick(const gple_element* Elements, const double mass, const double dt, gple_points* pts, const unsigned flags)
+	{
+		if constexpr (NumPES == 2) return gple_evolve(context(), Elements, pes_model(), mass, dt, pts, flags);
+		else return gple_evolve_n(context(), static_cast<int>(NumPES), Elements, pes_model(), mass, dt, pts, flags);
+	}
 	/// new_point_predict (evolve.cpp:425-443) for all the given points of element (RowIndex, ColIndex) at once
 	inline Eigen::VectorXcd new_points_predict(const ElementPoints& points, const ClassicalVector<double>& mass, const double dt,
 		const TrainingKernels& AllKernels, const std::size_t RowIndex, const std::size_t ColIndex)
 	{
 		Eigen::VectorXcd result(static_cast<Eigen::Index>(points.size()));
-		if constexpr (NumPES == 2 && Dim == 1)
+		if constexpr (NumPES <= 3 && Dim == 1)
 		{
 			AllPoints probe;
 			probe(RowIndex, ColIndex) = points;
 			PackedPoints packed(probe);
 			const std::vector<gple_element> Elements = elements_of(AllKernels);
-			check(gple_evolve(context(), Elements.data(), pes_model(), mass[0], dt, packed.pts.data(), GPLE_EVOLVE_NEW_POINTS), context());
+			check(tick(Elements.data(), mass[0], dt, packed.pts.data(), GPLE_EVOLVE_NEW_POINTS), context());
 			const std::vector<double>& rho = packed.rho[DistributionBatcher::element_index(RowIndex, ColIndex)];
 			for (std::size_t i = 0; i < points.size(); i++) result[static_cast<Eigen::Index>(i)] = std::complex<double>(rho[2 * i], rho[2 * i + 1]);
 		}
 		else
-			assert(!"NO INSTANTATION OF MORE THAN TWO LEVEL SYSTEM NOW"); // evolve.cpp:367-371
+			assert(!"NO INSTANTATION OF MORE THAN THREE LEVEL SYSTEM NOW"); // evolve.cpp:367-371 stops at two; the library goes to three
 		return result;
 	}
 } // namespace gple_host
@@ -118,15 +125,15 @@ namespace gple_host
 /// evolve(density, mass, dt, distribution) with distribution = the cut-off prediction of `AllKernels` (main.cpp:75-101), on the device
 inline void evolve(AllPoints& density, const ClassicalVector<double>& mass, const double dt, const TrainingKernels& AllKernels)
 {
-	if constexpr (NumPES == 2 && Dim == 1)
+	if constexpr (NumPES <= 3 && Dim == 1)
 	{
 		gple_host::PackedPoints packed(density);
 		const std::vector<gple_element> Elements = gple_host::elements_of(AllKernels);
-		gple_host::check(gple_evolve(gple_host::context(), Elements.data(), gple_host::pes_model(), mass[0], dt, packed.pts.data(), 0), gple_host::context());
+		gple_host::check(gple_host::tick(Elements.data(), mass[0], dt, packed.pts.data(), 0), gple_host::context());
 		packed.unpack(density);
 	}
 	else
-		assert(!"NO INSTANTATION OF MORE THAN TWO LEVEL SYSTEM NOW"); // evolve.cpp:367-371
+		assert(!"NO INSTANTATION OF MORE THAN THREE LEVEL SYSTEM NOW"); // evolve.cpp:367-371 stops at two
 }
 
 /// new_point_predict with the kernels in place of the callback (one point: a batch of one)

@@ -210,9 +210,9 @@ int main(int argc, char** argv)
 	// output.cpp:262-290
 	std::printf("rescale %.17g %.17g\n", (*all_kernels)(0)->get_rescale_factor(), (*all_kernels)(1, 0)->get_rescale_factor());
 
-	// main.cpp:140-143: the tick's three calls, the kernels standing where predict_distribution stood (two-level system: what the
-	// reference instantiates, evolve.cpp:367-371)
-	if constexpr (NumPES == 2)
+	// main.cpp:140-143: the tick's three calls, the kernels standing where predict_distribution stood (the printed lines are checked for the
+	// two-level system the reference instantiates, evolve.cpp:367-371; compiled for three levels the same calls go to gple_evolve_n)
+	if constexpr (NumPES <= 3)
 	{
 		ClassicalVector<double> mass;
 		mass[0] = 2000.0;
@@ -234,7 +234,7 @@ int main(int argc, char** argv)
 		std::printf("evolve_extra_sizes %zu %zu %zu\n", moved_extra(0).size(), moved_extra(1, 0).size(), moved_extra(1).size());
 		const QuantumStorage<bool> IsSmall = is_very_small(density, mass, dt, *all_kernels);
 		std::printf("is_small %d %d %d\n", IsSmall(0) ? 1 : 0, IsSmall(1, 0) ? 1 : 0, IsSmall(1) ? 1 : 0);
-		const std::complex<double> np = new_point_predict(r0, mass, dt, *all_kernels, 1, 1);
+		const std::complex<double> np = new_point_predict(r0, mass, dt, *all_kernels, NumPES - 1, NumPES - 1);
 		std::printf("new_point_11 %.17g %.17g\n", np.real(), np.imag());
 		// mc.cpp:118-165 for all points of rho_00 at once, then the selection body of mc.cpp:349-369
 		EigenVector<ClassicalPhaseVector> start;
