@@ -1174,6 +1174,28 @@ extern "C"
 			a.complex_deriv = cplx ? 1 : 0;
 			if (cplx) std::memcpy(a.dspec, f->dspec, sizeof(a.dspec));
 		}
+		// How much of the variance contraction the caller's outputs need (GPLE_PREDICT_SKIP=0: always all of it, for A/B runs).  The objective
+		// of opt.cpp:441-482 asks for Error (+ ErrorDerivatives) only: Error uses the UNCUT mean (kernel.cpp:522) — no contraction at all, every
+		// value-only evaluation of the derivative-free searches; ErrorDerivatives use the cut one (:527), where the variance only decides the
+		// cut-off factor — and a point with |mu|^2 >= 4 k(x*,x*) >= 4 var has factor 1 (kernel.h:301-332) whatever q is.
+		static const bool skip_ok = [] {
+			const char* e = getenv("GPLE_PREDICT_SKIP");
+			return e == nullptr || atoi(e) != 0;
+		}();
+		if (skip_ok && !variance && !cutoff_prediction)
+		{
+			if (!want_deriv) a.mean_only = 1;
+			else
+			{
+				a.cut_thr = 4.0 * f->self;
+				if (!ctx->prune_stats)
+				{
+					GPLE_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->prune_stats), 4 * sizeof(unsigned long long)));
+					GPLE_HIP(ctx, hipMemsetAsync(ctx->prune_stats, 0, 4 * sizeof(unsigned long long), st));
+				}
+				a.prune_stats = ctx->prune_stats;
+			}
+		}
 		int chunk_rows = 0;
 		bool few_rows = false;
 		Scratch kstar(ctx);

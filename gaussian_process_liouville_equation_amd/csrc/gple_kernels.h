@@ -155,6 +155,11 @@ namespace gple
 		double* q;       // m_rows: || T k*_m ||^2
 		double* mu;      // m_rows: k*_m . v
 		SEParamSet ps;
+		// What the caller consumes decides how much of the variance contraction has to run (gple_predict.hip, launch_predict_q):
+		int mean_only;                   // 1: neither the variance nor the cut-off factor is consumed (PredictiveKernel's Error alone, kernel.cpp:522,
+		                                 //    uses the UNCUT mean): no K*, no contraction, q = 0
+		double cut_thr;                  // > 0: the variance only decides the cut-off factor (ErrorDerivatives, kernel.cpp:527): a point with
+		                                 //    |mu|^2 >= cut_thr = 4 k(x*,x*) >= 4 var has factor 1 whatever q is (kernel.h:301-332) and is not contracted
 		double prune_thr;                // > 0: rows with |k*|^2 below it are not contracted (gple_predict.hip, Prune)
 		unsigned long long* prune_stats; // device, 4 words: [0] += ceil(live rows / 128), [1] += rows / 128, [2] work-queue counter, [3] live-row count
 	};

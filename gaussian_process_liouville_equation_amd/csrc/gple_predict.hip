@@ -125,23 +125,28 @@ namespace gple
 					const bool valid = pk < a.N;
 					const int pc = valid ? pk : 0;
 					const double xk = a.Xt[2 * pc], pkv = a.Xt[2 * pc + 1];
-					const double d0 = (xm - xk) * rl0, d1 = (pm - pkv) * rl1;
-					const double g = exp_nonpos(-0.5 * (d0 * d0 + d1 * d1));
+					// (every product and sum of a K* entry explicitly rounded or fused: left to the compiler, d0 * d0 + d1 * d1 contracts into an fma
+					// in the instantiations where d0 * d0 has no second use and does not in the derivative ones — K* then differs by an ulp between
+					// the passes of one predict)
+					const double d0 = __dmul_rn(xm - xk, rl0), d1 = __dmul_rn(pm - pkv, rl1);
+					const double g = exp_nonpos(__dmul_rn(-0.5, fma(d0, d0, __dmul_rn(d1, d1))));
 					const double delta = (xm == xk && pm == pkv) ? n2 : 0.0; // delta_kernel: exact equality, kernel.cpp:26
-					const double val = valid ? amp * (g + delta) : 0.0;
+					const double val = valid ? __dmul_rn(amp, g + delta) : 0.0;
 					if constexpr (MODE != 2) mu = fma(val, a.v[k], mu);
 					if constexpr (MODE == 1) nrm = fma(val, val, nrm);
 					if constexpr (DERIV == 2)
 					{
 #pragma unroll
 						for (int ip = 0; ip < 8; ++ip) dacc[ip] = fma(val, a.dv[static_cast<long>(ip) * a.n_total + k], dacc[ip]);
-						const double gw = valid ? g * a.v[k] : 0.0;
-						const double f0 = d0 * d0 * rl0, f1 = d1 * d1 * rl1;
+						// (explicitly rounded products and fused multiply-adds: the planes must not depend on which MODE instantiation the
+						// compiler is contracting — the lean and the full predict are compared bit for bit)
+						const double gw = valid ? __dmul_rn(g, a.v[k]) : 0.0;
+						const double f0 = __dmul_rn(__dmul_rn(d0, d0), rl0), f1 = __dmul_rn(__dmul_rn(d1, d1), rl1);
 #pragma unroll
 						for (int ip = 0; ip < 6; ++ip)
 						{
 							const DSpec& sp = a.dspec[ip].b[type_m + type_k];
-							const double fac = sp.active ? sp.amp * (sp.c0 + sp.c1 * (sp.dim == 0 ? f0 : f1)) : 0.0;
+							const double fac = sp.active ? __dmul_rn(sp.amp, fma(sp.c1, sp.dim == 0 ? f0 : f1, sp.c0)) : 0.0;
 							dacc[8 + ip] = fma(gw, fac, dacc[8 + ip]);
 						}
 					}
@@ -150,9 +155,9 @@ namespace gple
 #pragma unroll
 						for (int ip = 0; ip < 4; ++ip) dacc[ip] = fma(val, a.dv[static_cast<long>(ip) * a.n_total + k], dacc[ip]);
 						// dK*/dl_d = K* ((x*_d - x_d)/l_d)^2 / l_d  (test-set branch: K* with its noise delta, kernel.cpp:196)
-						const double vk = val * a.v[k];
-						dacc[4] = fma(vk, d0 * d0 * rl0, dacc[4]);
-						dacc[5] = fma(vk, d1 * d1 * rl1, dacc[5]);
+						const double vk = __dmul_rn(val, a.v[k]);
+						dacc[4] = fma(vk, __dmul_rn(__dmul_rn(d0, d0), rl0), dacc[4]);
+						dacc[5] = fma(vk, __dmul_rn(__dmul_rn(d1, d1), rl1), dacc[5]);
 					}
 					if constexpr (MODE != 1) out[static_cast<long>(e) * rows] = val;
 				}
@@ -229,6 +234,34 @@ namespace gple
 				double sq = 0.0;
 				for (int ky = 0; ky < planes; ++ky) sq += nrm_part[static_cast<long>(ky) * m_rows + row];
 				live = !(sq < thr); // NaN counts as live
+			}
+			const unsigned long long mask = __ballot(live);
+			const int lane = threadIdx.x & 63;
+			int base = 0;
+			if (lane == 0 && mask) base = atomicAdd(n_live, __popcll(mask));
+			base = __shfl(base, 0);
+			if (row < m_rows)
+			{
+				const int p = live ? base + __popcll(mask & ((1ULL << lane) - 1)) : -1;
+				pos[row] = p;
+				if (live) list[p] = row;
+			}
+		}
+		// The same list for the cut-off-certain skip (PredictArgs::cut_thr): a POINT is live when |mu|^2 < thr (NaN counts as live); both typed
+		// rows of a complex point go together.  mu: the summed means (m_rows); rows at or beyond M (padding) are dead.
+		__global__ void __launch_bounds__(256) compact_by_mean_kernel(const double* __restrict__ mu, int m_rows, int m_split, int M, double thr,
+			int* __restrict__ list, int* __restrict__ pos, int* __restrict__ n_live)
+		{
+			const int row = blockIdx.x * 256 + threadIdx.x;
+			bool live = false;
+			if (row < m_rows)
+			{
+				const int pt = row >= m_split ? row - m_split : row;
+				if (pt < M)
+				{
+					const double re = mu[pt], im = m_split < m_rows ? mu[m_split + pt] : 0.0;
+					live = !(re * re + im * im >= thr);
+				}
 			}
 			const unsigned long long mask = __ballot(live);
 			const int lane = threadIdx.x & 63;
@@ -781,7 +814,7 @@ namespace gple
 		*chunk_rows = static_cast<int>(rows);
 		return rows * a.n_total + static_cast<size_t>(gen_ksplit(a.m_rows)) * a.m_rows * (a.dv ? (a.complex_deriv ? 15 : 7) : 1)
 			+ (small ? rows * a.n_total : 0) + static_cast<size_t>(ROWNORM_SPLIT_MAX) * a.m_rows
-			+ (a.prune_thr > 0.0 ? (static_cast<size_t>(gen_ksplit(a.m_rows)) + 1) * a.m_rows + 64 : 0); // + K*^2 sums, list and positions (2 ints per row)
+			+ (a.prune_thr > 0.0 || a.cut_thr > 0.0 || a.mean_only ? (static_cast<size_t>(gen_ksplit(a.m_rows)) + 1) * a.m_rows + 64 : 0); // + K*^2 sums, list and positions (2 ints per row)
 	}
 
 	bool predict_is_few(const PredictArgs& a)
@@ -840,8 +873,26 @@ namespace gple
 		// groups per row block: by the number of row blocks (rownorm_split); the value of q does not depend on it (virtual groups)
 		int split = small ? 1 : rownorm_split(a.m_rows, a.n_total);
 		double* qpart = Z + (small ? static_cast<size_t>(chunk_rows) * a.n_total : 0);
+		const int dplanes = a.dv ? (a.complex_deriv ? 15 : 7) : 1;
+		if (a.mean_only)
+		{
+			// only the (uncut) mean is consumed: one generation pass without storing K*, no contraction
+			double* nrm_part = qpart + static_cast<size_t>(VG) * a.m_rows;
+			const dim3 ggrid(a.m_rows / 128, ksplit);
+			const int* none = nullptr;
+			if (a.dv && a.complex_deriv) hipLaunchKernelGGL((kstar_gen_kernel<2, 1>), ggrid, dim3(128), 0, s, a, 0, a.m_rows, Ks, mu_part, nrm_part, none, none);
+			else if (a.dv) hipLaunchKernelGGL((kstar_gen_kernel<1, 1>), ggrid, dim3(128), 0, s, a, 0, a.m_rows, Ks, mu_part, nrm_part, none, none);
+			else hipLaunchKernelGGL((kstar_gen_kernel<0, 1>), ggrid, dim3(128), 0, s, a, 0, a.m_rows, Ks, mu_part, nrm_part, none, none);
+			const hipError_t e = hipMemsetAsync(a.q, 0, static_cast<size_t>(a.m_rows) * sizeof(double), s);
+			if (e != hipSuccess) return e;
+			hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.mu);
+			if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, dplanes), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.dacc);
+			return hipGetLastError();
+		}
+		// the variance only decides the cut-off factor: points whose mean is large enough for factor 1 whatever the variance are not contracted
+		const bool cut_only = a.cut_thr > 0.0 && !small && a.prune_stats != nullptr;
 		// far-row pruning (Prune): streaming kernels only, no derivative pass
-		const bool prune = a.prune_thr > 0.0 && !a.dv && !small && a.prune_stats != nullptr;
+		const bool prune = !cut_only && a.prune_thr > 0.0 && !a.dv && !small && a.prune_stats != nullptr;
 		auto launch_rownorm = [&](bool queue_mode, dim3 grid, int rows, double* qdst, const Prune& pr) {
 			auto launch = [&](auto full_kernel, auto queue_kernel) {
 				if (queue_mode) hipLaunchKernelGGL(queue_kernel, grid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
@@ -851,11 +902,13 @@ namespace gple
 			else if (variant == 2) launch(rownorm2_kernel<4, 4, false>, rownorm2_kernel<4, 4, true>);
 			else launch(rownorm_kernel<8, 16, false>, rownorm_kernel<8, 16, true>);
 		};
-		if (prune)
+		if (prune || cut_only)
 		{
 			// 1. partial means and partial sums of K*^2 of every row (no K* stored); 2. the live rows -> list; 3. per chunk OF THE LIST:
 			// K* of the listed rows, row norms by a work queue; 4. q back to the rows.  The number of live rows stays on the device:
 			// launches that turn out to have nothing to do return at once.
+			// cut_only: step 1 also forms the derivative planes, the means are summed at once and step 2 lists the points whose |mu|^2 leaves
+			// the cut-off factor open.
 			double* nrm_part = qpart + static_cast<size_t>(VG) * a.m_rows;
 			int* list = reinterpret_cast<int*>(nrm_part + static_cast<size_t>(ksplit) * a.m_rows);
 			int* pos = list + a.m_rows;
@@ -863,9 +916,18 @@ namespace gple
 			int* queue = reinterpret_cast<int*>(a.prune_stats + 2);
 			hipError_t e = hipMemsetAsync(n_live, 0, sizeof(int), s);
 			if (e != hipSuccess) return e;
-			hipLaunchKernelGGL((kstar_gen_kernel<0, 1>), dim3(a.m_rows / 128, ksplit), dim3(128), 0, s, a, 0, a.m_rows, Ks, mu_part, nrm_part,
-				static_cast<const int*>(nullptr), static_cast<const int*>(nullptr));
-			hipLaunchKernelGGL(compact_rows_kernel, dim3((a.m_rows + 255) / 256), dim3(256), 0, s, nrm_part, ksplit, a.m_rows, a.prune_thr, list, pos, n_live);
+			const dim3 ggrid(a.m_rows / 128, ksplit);
+			const int* none = nullptr;
+			if (a.dv && a.complex_deriv) hipLaunchKernelGGL((kstar_gen_kernel<2, 1>), ggrid, dim3(128), 0, s, a, 0, a.m_rows, Ks, mu_part, nrm_part, none, none);
+			else if (a.dv) hipLaunchKernelGGL((kstar_gen_kernel<1, 1>), ggrid, dim3(128), 0, s, a, 0, a.m_rows, Ks, mu_part, nrm_part, none, none);
+			else hipLaunchKernelGGL((kstar_gen_kernel<0, 1>), ggrid, dim3(128), 0, s, a, 0, a.m_rows, Ks, mu_part, nrm_part, none, none);
+			if (cut_only)
+			{
+				hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.mu);
+				hipLaunchKernelGGL(compact_by_mean_kernel, dim3((a.m_rows + 255) / 256), dim3(256), 0, s, a.mu, a.m_rows, a.m_split, a.M, a.cut_thr, list, pos, n_live);
+			}
+			else
+				hipLaunchKernelGGL(compact_rows_kernel, dim3((a.m_rows + 255) / 256), dim3(256), 0, s, nrm_part, ksplit, a.m_rows, a.prune_thr, list, pos, n_live);
 			// the number of live row blocks is only known on the device: the finest units (most groups per block that still hold a snake pair
 			// of N-tiles each) keep the last round of the queue short whatever it turns out to be — 93 live blocks in 2 groups fill 186 of 256
 			// CUs once, in 8 groups they make 2.9 rounds of an eighth
@@ -887,7 +949,7 @@ namespace gple
 				chunk_timer_stop(ctx);
 			}
 			hipLaunchKernelGGL(scatter_q_kernel, dim3((a.m_rows + 255) / 256), dim3(256), 0, s, qpart, static_cast<long>(a.m_rows), pos, a.m_rows, a.q, n_live,
-				a.prune_stats);
+				cut_only ? static_cast<unsigned long long*>(nullptr) : a.prune_stats); // (the far-row statistics count far rows only)
 		}
 		else
 		{
@@ -917,9 +979,9 @@ namespace gple
 			}
 			if (!small) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, qpart, a.m_rows, VG, a.q); // the VG planes, in order
 		}
-		// a.mu receives plane 0 (the mean); with derivatives a.dacc receives all 7 planes (plane 0 = the mean again)
-		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.mu);
-		if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, a.complex_deriv ? 15 : 7), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.dacc);
+		// a.mu receives plane 0 (the mean); with derivatives a.dacc receives all 7 / 15 planes (plane 0 = the mean again)
+		if (!cut_only) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.mu);
+		if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, dplanes), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.dacc);
 		return hipGetLastError();
 	}
 } // namespace gple

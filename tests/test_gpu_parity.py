@@ -547,3 +547,31 @@ def test_far_row_pruning_edge_cases(gpu):
         assert np.array_equal(a[k], b[k]), k
     assert np.all(a["variance"] == THETA_R[0] ** 2 * (1 + THETA_R[3] ** 2))
     fit.release()
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_predict_skips_what_nobody_consumes(gpu, cplx):
+    """A predict that is only asked for Error (+ ErrorDerivatives) — the objective of opt.cpp:441-482 — skips the variance contraction where it
+    cannot matter: Error uses the uncut mean (kernel.cpp:522: no contraction at all), ErrorDerivatives use the cut mean (:527), and a point with
+    |mu|^2 >= 4 k(x*,x*) has cut-off factor 1 whatever its variance (kernel.h:301-332).  Same scalars, bit for bit, as the call that also asks
+    for the variance (which contracts every row); sizes on the streaming path (not the few-rows GEMM path)."""
+    from tests.test_gpu_configs import config_inputs, extra_set, THETA_C, THETA_R
+    N = 2048
+    X, y, _, _ = config_inputs(N, 8, 31, cplx=cplx)
+    Xe, ye = extra_set(X, 32, cplx)           # 5N points around the packet: about half of them with |mu|^2 >= 4 k(x*,x*)
+    theta = list(THETA_C if cplx else THETA_R)
+    theta[-1] = 0.05
+    fit = (gpu.complex_fit if cplx else gpu.real_fit)(theta, X, y, c.CALC_ERROR | c.CALC_DERIVATIVE)
+    pred = gpu.complex_predict if cplx else gpu.real_predict
+    lab = ye if cplx else ye.real
+    for flags in (0, c.CALC_DERIVATIVE):
+        lean = pred(fit, Xe, flags=flags | c.PREDICT_FULL, labels=lab, want=())
+        full = pred(fit, Xe, flags=flags | c.PREDICT_FULL, labels=lab, want=("variance", "cutoff"))
+        assert lean["error"] == full["error"] and np.isfinite(lean["error"])
+        if flags:
+            assert np.array_equal(lean["error_derivative"], full["error_derivative"]) and np.all(np.isfinite(lean["error_derivative"]))
+            # the skip has something to skip and something to keep: both classes of points are present
+            mu2 = np.abs(pred(fit, Xe, want=("prediction",))["prediction"]) ** 2
+            kss = theta[0] ** 2 * ((theta[1] ** 2 + theta[4] ** 2 + theta[7] ** 2) if cplx else (1 + theta[3] ** 2))
+            assert 0.15 < (mu2 >= 4 * kss).mean() < 0.85
+    fit.release()
