@@ -797,7 +797,10 @@ namespace gple
 			const bool fits = static_cast<size_t>(a.m_rows) * a.n_total <= SMALL_M_Z_DOUBLES;
 			const char* force = getenv("GPLE_PREDICT_SMALL_M"); // "0" / "1": A/B runs and the path-against-path parity test
 			if (force && (force[0] == '0' || force[0] == '1')) return force[0] == '1' && fits;
-			return static_cast<long>(a.m_rows / BM) * (a.n_total / BN) <= SMALL_M_WORK && fits;
+			// one N-tile (n <= 256): the streaming kernel has nothing to split, but from 64 row blocks on it fills a quarter of the chip with
+		// 16-step workgroups and beats the GEMM + column-sum pair, which moves K* and Z through HBM three times (C1: 47 vs 58 us)
+		if (a.n_total / BN == 1 && a.m_rows / BM >= 64) return false;
+		return static_cast<long>(a.m_rows / BM) * (a.n_total / BN) <= SMALL_M_WORK && fits;
 		}
 	} // namespace
 
