@@ -728,7 +728,11 @@ def opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev):
     from gaussian_process_liouville_equation_amd import kernels as K
     N = WORKLOADS["C4opt"][0]
     elems = [("real", 0), ("complex", 1), ("real", 2)]  # reference order (0,0), (1,0), (1,1)
-    mine = [i for i in range(3) if parallel.element_owner(i, world) == rank and args.opt_only in (None, i)]
+    # one rank: the three elements on three streams.  Several ranks: every rank holds all three objectives and evaluates ITS PART of each
+    # (gple_objective_eval_part: the N^3 derivative products of its parameters, its share of the extra points; fits replicated) — dealing
+    # whole elements to ranks buys nothing here, the complex element alone is the whole step — and one all-reduce of 3 x 9 doubles adds them up
+    split = world > 1 and args.shard == "grid"
+    mine = [i for i in range(3) if (split or parallel.element_owner(i, world) == rank) and args.opt_only in (None, i)]
     pool = K.ApiPool(n=max(1, len(mine)), device=dev)
     objs, thetas = {}, {}
     for slot, i in enumerate(mine):
@@ -741,9 +745,18 @@ def opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev):
         thetas[i] = theta
 
     def step():
-        res = pool.map(lambda api, i: objs[i](thetas[i], want_grad=True), mine)
+        if split:
+            res = pool.map(lambda api, i: objs[i].part(thetas[i], rank, world, want_grad=True), mine)
+        else:
+            res = pool.map(lambda api, i: objs[i](thetas[i], want_grad=True), mine)
         vals = {i: [v] + list(g) + [0.0] * (8 - len(g)) for i, (v, g) in zip(mine, res)}
-        allv = parallel.allgather_element_scalars(vals, 3, 9, device="cuda" if (world > 1 and args.backend == "nccl") else "cpu")
+        if split:  # every rank contributes to every slot: a plain sum (make_normal, opt.cpp:420-431, after it)
+            buf = torch.zeros(3, 9, dtype=torch.float64, device="cuda" if args.control == "nccl" else "cpu")
+            for i, v in vals.items():
+                buf[i] = torch.as_tensor(v, dtype=torch.float64)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            return torch.nan_to_num(buf, nan=1.7976931348623157e308, posinf=1.7976931348623157e308, neginf=1.7976931348623157e308)
+        allv = parallel.allgather_element_scalars(vals, 3, 9, device="cuda" if (world > 1 and args.control == "nccl") else "cpu")
         return allv
 
     for _ in range(args.warmup):
@@ -792,7 +805,9 @@ def opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev):
         "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"C4opt: opt.cpp inner loop, full_loose value+gradient of 2 real + 1 complex element, N={N}, 5N={5 * N} extra points each",
-                   "N": N, "M": 5 * N, "parallelism": ("3 elements on 3 HIP streams of one GPU" if args.opt_only is None else f"element {args.opt_only} alone") if world == 1 else f"elements dealt out over {world} ranks, scalars all-reduced"},
+                   "N": N, "M": 5 * N, "parallelism": ("3 elements on 3 HIP streams of one GPU" if args.opt_only is None else f"element {args.opt_only} alone") if world == 1 else
+                   (f"every element's gradient split over {world} ranks (gple_objective_eval_part: derivative products by parameter, extra points by rows, fits replicated), one all-reduce of 27 doubles"
+                    if split else f"elements dealt out over {world} ranks, scalars all-reduced")},
         "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<128,128> (dK * K^-1 of the LOOCV gradient, kernel.cpp:354; complex element: the two half-size block products per parameter)", "achieved": round(achieved, 3),
                      "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
                      "traffic": traffic_for("C4opt" if args.opt_only is None else f"C4opt_only{args.opt_only}", world)[0],

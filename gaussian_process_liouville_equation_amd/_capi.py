@@ -204,7 +204,7 @@ GPLE_SYMBOLS = [
     "real_gram", "complex_gram", "cutoff_factor", "predict_batch", "shard_bounds", "set_allgather_function", "real_predict_sharded", "complex_predict_sharded", "real_predict_dealt", "complex_predict_dealt", "deal_share",
     "real_fit_create", "real_fit_get_scalars", "real_fit_retain", "real_fit_release", "real_fit_size", "real_fit_get", "real_predict",
     "complex_fit_create", "complex_fit_get_scalars", "complex_fit_retain", "complex_fit_release", "complex_fit_size", "complex_fit_get",
-    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_release", "minimize_neldermead", "objective_minimize_neldermead", "minimize_direct_l", "objective_minimize_direct_l", "minimize_auglag_eq", "pes_adiabatic", "evolve", "evolve_n", "pes_adiabatic_n", "markov_chain", "markov_chain_trace", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
+    "complex_predict", "loose_function", "objective_create", "objective_eval", "objective_eval_part", "objective_release", "minimize_neldermead", "objective_minimize_neldermead", "minimize_direct_l", "objective_minimize_direct_l", "minimize_auglag_eq", "pes_adiabatic", "evolve", "evolve_n", "pes_adiabatic_n", "markov_chain", "markov_chain_trace", "nlml", "nlml_predict", "nlml_cross", "nlml_cross_predict",
 ]
 
 
@@ -268,6 +268,15 @@ class _Objective:
         val = C.c_double()
         grad = np.empty(len(x)) if want_grad else None
         self.api._check(self.api.lib.gple_objective_eval(self.handle, _ptr(x), len(x), C.cast(C.byref(val), _dp), _ptr(grad)))
+        return val.value, grad
+
+    def part(self, x, part, nparts, want_grad=True):
+        """gple_objective_eval_part: this rank's share of the value and gradient (sum over the parts = the whole; make_normal after the sum)"""
+        x = _f64(x)
+        val = C.c_double()
+        grad = np.empty(len(x)) if want_grad else None
+        self.api.lib.gple_objective_eval_part.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_int, C.c_int, _dp, _dp]
+        self.api._check(self.api.lib.gple_objective_eval_part(self.handle, _ptr(x), len(x), int(part), int(nparts), C.cast(C.byref(val), _dp), _ptr(grad)))
         return val.value, grad
 
     def release(self):

@@ -387,6 +387,11 @@ namespace
 			const double* Dd = D.p + d * n2;
 			GPLE_HIP(ctx, launch_gemv(st, Dd, nt, nt, f->v, 1.0, part.p, tvec.p));
 			GPLE_HIP(ctx, launch_gemv(st, f->W, nt, nt, tvec.p, -1.0, part.p, dv + static_cast<size_t>(1 + d) * nt));
+			if (!(ctx->deriv_mask >> (1 + d) & 1u)) // another rank forms this parameter's diag(W dK W) (gple_objective_eval_part); (dW) y above is needed by every rank's predict
+			{
+				GPLE_HIP(ctx, hipMemsetAsync(dwd.p + static_cast<size_t>(1 + d) * nt, 0, static_cast<size_t>(nt) * sizeof(double), st));
+				continue;
+			}
 			GemmDesc g{};
 			g.A = Dd, g.lda = nt, g.B = f->W, g.ldb = nt, g.C = C.p, g.ldc = nt;
 			g.M = nt, g.N = nt, g.K = nt, g.batch = 1, g.alpha = 1.0, g.beta = 0.0, g.krange = K_FULL, g.lower_only = 0;
@@ -496,6 +501,12 @@ namespace
 			GPLE_HIP(ctx, launch_typed_deriv_gram(st, f->Xt, f->N, Np, nt, f->dspec[ip - 1], D.p));
 			GPLE_HIP(ctx, launch_gemv(st, D.p, nt, nt, f->v, 1.0, part.p, tvec.p));
 			GPLE_HIP(ctx, launch_gemv(st, f->W, nt, nt, tvec.p, -1.0, part.p, dw + static_cast<size_t>(ip) * nt));
+			if (!(ctx->deriv_mask >> ip & 1u)) // another rank forms this parameter's diagonals (gple_objective_eval_part)
+			{
+				GPLE_HIP(ctx, hipMemsetAsync(dwd.p + static_cast<size_t>(ip) * nt, 0, static_cast<size_t>(nt) * sizeof(double), st));
+				GPLE_HIP(ctx, hipMemsetAsync(dwx.p + static_cast<size_t>(ip) * Np, 0, static_cast<size_t>(Np) * sizeof(double), st));
+				continue;
+			}
 			// Only diag(M dC M) and the diagonal of its Re-Im block are consumed, and every dC of a sub-kernel parameter has one zero
 			// diagonal block (build_dspecs: C_yy does not depend on the R kernel's parameters, C_xx not on the I kernel's).  With A the
 			// non-zero diagonal block, B the off-diagonal one and M_a / M_b the matching row halves of M,
@@ -2179,8 +2190,31 @@ extern "C"
 	// loose_function (opt.cpp:441-482).  io = 0: host pointers; io = GPLE_IO_DEVICE: everything but x / value / grad is resident
 	// (lab = real parts of y_extra, the label vector of the real kernel's PredictiveKernel, opt.cpp:451)
 	static int loose_eval(gple_ctx* ctx, const double* x, size_t n, const double* X, const double* y, size_t N, const double* X_extra,
-		const double* y_extra, const double* lab, size_t M_extra, unsigned io, double* value, double* grad)
+		const double* y_extra, const double* lab, size_t M_extra, unsigned io, double* value, double* grad, int part = 0, int nparts = 1)
 	{
+		// part / nparts > 1 (gple_objective_eval_part): this call forms the N^3 products of the parameters ip with ip % nparts == part (the cheap
+		// first and last parameters belong to part 0) and predicts the rows [lo, hi) of the extra set; the LOOCV error counts on part 0; the
+		// sum over the parts is the whole objective and gradient, make_normal is the caller's after that sum
+		if (nparts > 1)
+		{
+			const size_t per = (M_extra + nparts - 1) / nparts, lo = std::min(M_extra, per * part), hi = std::min(M_extra, lo + per);
+			X_extra += 2 * lo, y_extra += 2 * lo, lab += lo, M_extra = hi - lo;
+			unsigned mask = 0;
+			for (size_t ip = 0; ip < n; ++ip)
+				if ((ip == 0 || ip == n - 1) ? part == 0 : static_cast<int>(ip % nparts) == part) mask |= 1u << ip;
+			std::lock_guard<std::mutex> lk(ctx->mu);
+			ctx->deriv_mask = mask;
+		}
+		struct MaskReset
+		{
+			gple_ctx* c;
+			~MaskReset()
+			{
+				std::lock_guard<std::mutex> lk(c->mu);
+				c->deriv_mask = 0xFFu;
+			}
+		} mask_reset{ctx};
+		const unsigned owned = nparts > 1 ? ctx->deriv_mask : 0xFFu;
 		const unsigned flags = GPLE_CALC_ERROR | (grad ? GPLE_CALC_DERIVATIVE : 0u);
 		gple_predict_scalars ps;
 		double result = 0.0;
@@ -2197,9 +2231,9 @@ extern "C"
 			gple_real_fit_release(fit);
 			GPLE_TRY(st);
 			if (M_extra) predict_scalars_from_host(ctx, true, want_deriv, false, &ps);
-			result = sc.error + (M_extra ? ps.error : 0.0);
+			result = (part == 0 ? sc.error : 0.0) + (M_extra ? ps.error : 0.0);
 			if (grad)
-				for (int i = 0; i < 4; ++i) grad[i] = sc.error_derivative[i] + (M_extra ? ps.error_derivative[i] : 0.0);
+				for (int i = 0; i < 4; ++i) grad[i] = ((owned >> i & 1u) ? sc.error_derivative[i] : 0.0) + (M_extra ? ps.error_derivative[i] : 0.0);
 		}
 		else
 		{
@@ -2211,17 +2245,20 @@ extern "C"
 			gple_complex_fit_release(fit);
 			GPLE_TRY(st);
 			if (M_extra) predict_scalars_from_host(ctx, true, want_deriv, true, &ps);
-			result = sc.error + (M_extra ? ps.error : 0.0);
+			result = (part == 0 ? sc.error : 0.0) + (M_extra ? ps.error : 0.0);
 			if (grad)
-				for (int i = 0; i < 8; ++i) grad[i] = sc.error_derivative[i] + (M_extra ? ps.error_derivative[i] : 0.0);
+				for (int i = 0; i < 8; ++i) grad[i] = ((owned >> i & 1u) ? sc.error_derivative[i] : 0.0) + (M_extra ? ps.error_derivative[i] : 0.0);
 		}
 		// make_normal, opt.cpp:420-431
 		auto make_normal = [](double& d) {
 			if (std::isnan(d) || std::isinf(d)) d = std::numeric_limits<double>::max();
 		};
-		make_normal(result);
-		if (grad)
-			for (size_t i = 0; i < n; ++i) make_normal(grad[i]);
+		if (nparts == 1)
+		{
+			make_normal(result);
+			if (grad)
+				for (size_t i = 0; i < n; ++i) make_normal(grad[i]);
+		}
 		*value = result;
 		return GPLE_OK;
 	}
@@ -2281,6 +2318,12 @@ extern "C"
 		if (!o || !x || !value || (n != 4 && n != 8)) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(o->ctx);
 		return loose_eval(o->ctx, x, n, o->X, o->y, o->N, o->Xe, o->ye, o->lab, o->M, GPLE_IO_DEVICE, value, grad);
+	}
+	int gple_objective_eval_part(gple_objective* o, const double* x, size_t n, int part, int nparts, double* value, double* grad)
+	{
+		if (!o || !x || !value || (n != 4 && n != 8) || nparts < 1 || part < 0 || part >= nparts) return GPLE_ERR_BAD_ARG;
+		GPLE_OPEN(o->ctx);
+		return loose_eval(o->ctx, x, n, o->X, o->y, o->N, o->Xe, o->ye, o->lab, o->M, GPLE_IO_DEVICE, value, grad, part, nparts);
 	}
 	int gple_objective_release(gple_objective* o)
 	{

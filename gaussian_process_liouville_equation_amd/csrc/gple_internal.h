@@ -76,6 +76,7 @@ namespace gple
 		// second stream + two events for the part of a fit that does not sit on the factorisation's critical path (created on
 		// first use by chol_inverse_factor; the main stream waits for the side work before anything reads its results)
 		hipStream_t side_stream = nullptr;
+		unsigned deriv_mask = 0xFFu; // which parameters' N^3 products a derivative fit forms (bit ip; gple_objective_eval_part splits them over ranks)
 		int side_attempts = 0;       // candidate streams tried until one ran beside the main stream (pick_side_stream)
 		bool side_overlaps = false;  // the chosen one did
 		hipEvent_t side_join = nullptr;

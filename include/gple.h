@@ -220,6 +220,13 @@ int gple_objective_create(gple_ctx* ctx, const double* X, const double* y, size_
 	size_t M_extra, gple_objective** out);
 /* loose_function(x, grad, params): n = 4 (real element) or 8 (complex element); grad may be NULL. */
 int gple_objective_eval(gple_objective* objective, const double* x, size_t n, double* value, double* grad);
+/* One rank's share of an evaluation, for a gradient split over the GPUs of a node (configs[3]: the opt.cpp loop on 4 GPUs, where the complex
+ * element alone is the whole step): every rank holds the objective (same data) and fits (replicated, like the grid-sharded predict); rank
+ * `part` of `nparts` forms the N^3 derivative products of the parameters ip with ip % nparts == part (the cheap first and last parameters on
+ * part 0), predicts its contiguous share of the extra points, and returns its partial value and gradient.  The sum over the parts (one
+ * all-reduce of n + 1 doubles) is gple_objective_eval's value and gradient up to the rounding of that sum; make_normal (opt.cpp:420-431:
+ * NaN / Inf -> DBL_MAX) is applied by the caller AFTER the sum.  nparts == 1 is gple_objective_eval. */
+int gple_objective_eval_part(gple_objective* objective, const double* x, size_t n, int part, int nparts, double* value, double* grad);
 int gple_objective_release(gple_objective* objective);
 
 /* ---- grid-sharded predict for C++ callers (output.cpp:181-233 over several GPUs) ---------------------- */

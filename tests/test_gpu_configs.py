@@ -517,3 +517,29 @@ def test_handles_survive_their_context(gpu):
     assert lib.gple_objective_eval(obj.handle, dp(th), 4, C.cast(C.byref(val), C.POINTER(C.c_double)), None) == 4
     obj.release()
     fit.release()  # the last handle frees the context
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_objective_parts_sum_to_the_whole(gpu, cplx):
+    """gple_objective_eval_part (the gradient of configs[3]'s opt loop split over the GPUs of a node): every rank fits, forms the N^3 derivative
+    products of its own parameters and predicts its share of the extra points; the parts' values and gradients sum to gple_objective_eval's —
+    here 1, 2, 3 and 4 parts evaluated one after the other on one GPU"""
+    N = 1024
+    X, y, _, _ = config_inputs(N, 8, 41, cplx=cplx)
+    Xe, ye = extra_set(X, 42, cplx)
+    theta = np.array(THETA_C if cplx else THETA_R)
+    theta[-1] = 0.05
+    obj = gpu.objective(X, np.asarray(y, dtype=complex), Xe, ye)
+    v, g = obj(theta, want_grad=True)
+    v0, _ = obj(theta, want_grad=False)
+    assert v0 == v
+    for nparts in (1, 2, 3, 4):
+        parts = [obj.part(theta, p, nparts, want_grad=True) for p in range(nparts)]
+        vs, gs = sum(p[0] for p in parts), np.sum([p[1] for p in parts], axis=0)
+        assert abs(vs - v) <= 1e-12 * abs(v), nparts
+        assert np.abs(gs - g).max() <= 1e-11 * np.abs(g).max(), nparts
+        if nparts > 1:  # the parts really are parts: nobody but part 0 reports the LOOCV error, every rank a different slice of the gradient
+            assert parts[1][0] < 0.9 * v and np.abs(parts[1][1] - g).max() > 1e-3 * np.abs(g).max()
+        vals = [obj.part(theta, p, nparts, want_grad=False)[0] for p in range(nparts)]
+        assert abs(sum(vals) - v) <= 1e-12 * abs(v)
+    obj.release()
