@@ -13,8 +13,9 @@ reference (paths relative to /root/reference/gaussian_process_liouville_equation
     one tick of main()          main.cpp:143-176                     -> tick(): evolve density and extra points, refit
     the loop body of main()     main.cpp:136-186                     -> main_tick(): tick + element changes + the three re-optimisation rules
 The reference passes a per-point DistributionFunction (stdafx.h:155) into these loops; here `all_kernels` (a TrainingKernels)
-plays that role and every tick costs three batched predicts instead of 8 one-point predicts per sample (NumPES = 2: what the
-reference instantiates, evolve.cpp:367-371).
+plays that role and every tick costs one batched predict per element instead of 8 one-point predicts per sample.  NumPES = 2 is what
+the reference instantiates (evolve.cpp:367-371 asserts beyond); with all_kernels.num_pes = 3 the same functions run on the N-level
+back-propagation of gple_evolve_n and the six elements of a three-level density matrix.
 """
 import numpy as np
 
@@ -42,9 +43,9 @@ def _api(all_kernels, api):
     return K.default_api()
 
 
-def _points(density):
+def _points(density, num_pes=2):
     empty = (np.zeros((0, 2)), np.zeros(0, dtype=complex))
-    return {e: (density.get(e) if density.get(e) is not None else empty) for e in _ORDER}
+    return {e: (density.get(e) if density.get(e) is not None else empty) for e in element_order(num_pes)}
 
 
 def evolve(density, mass, dt, all_kernels, model=DAC, api=None):
@@ -168,8 +169,8 @@ def monte_carlo_selection(density, MCParams, all_kernels, seed, api=None):
     seeds = _Seeds(seed)
     fits = _fits(all_kernels)
     out = {}
-    for e, (iPES, jPES) in enumerate(_ORDER):
-        pts = _points(density)[(iPES, jPES)]
+    for e, (iPES, jPES) in enumerate(element_order(all_kernels.num_pes)):
+        pts = _points(density, all_kernels.num_pes)[(iPES, jPES)]
         if len(pts[0]) == 0:
             out[(iPES, jPES)] = pts
             continue
@@ -183,18 +184,21 @@ def new_point_predict(r, iPES, jPES, mass, dt, all_kernels, model=DAC, api=None)
     """evolve.cpp:425-443 at all points r (n, 2) at once: what element (iPES, jPES) would be there after one more tick according to
     the current fits of all elements (three-branch back-propagation, no exact density); 0 where the point does not couple."""
     r = np.asarray(r, dtype=float).reshape(-1, 2)
-    dens = _points({})
+    dens = _points({}, all_kernels.num_pes)
     dens[(iPES, jPES)] = (r, np.zeros(len(r), dtype=complex))
-    return _api(all_kernels, api).evolve(_fits(all_kernels), model, float(np.ravel(mass)[0]), dt, dens, new_points=True)[(iPES, jPES)][1]
+    a = _api(all_kernels, api)
+    if all_kernels.num_pes != 2:  # the N-level back-propagation (gple_evolve_n, DESIGN.md §10)
+        return a.evolve_n(all_kernels.num_pes, _fits(all_kernels), model, float(np.ravel(mass)[0]), dt, dens, new_points=True)[(iPES, jPES)][1]
+    return a.evolve(_fits(all_kernels), model, float(np.ravel(mass)[0]), dt, dens, new_points=True)[(iPES, jPES)][1]
 
 
 def is_very_small(density, mass, dt, all_kernels, model=DAC, api=None):
     """evolve.cpp:445-478: {(iPES, jPES): bool}.  An element that has points is not small; one without is small when the new-point
     prediction stays below 1e-5 in modulus at every point of element (0, 0)."""
-    pts = _points(density)
+    pts = _points(density, all_kernels.num_pes)
     test = pts[(0, 0)][0]
     out = {}
-    for e in _ORDER:
+    for e in element_order(all_kernels.num_pes):
         out[e] = len(pts[e][0]) == 0 and bool(np.all(np.abs(new_point_predict(test, e[0], e[1], mass, dt, all_kernels, model, api)) ** 2 < 1e-10))
     return out
 
@@ -211,8 +215,8 @@ def generate_element_extra_points(points, NumExtraPoints, distribution, rng):
 def generate_extra_points(density, NumExtraPoints, all_kernels, rng, api=None):
     """mc.cpp:100-117 with the fits as the distribution (main.cpp:67,160,169,185)"""
     a, fits, out = _api(all_kernels, api), _fits(all_kernels), {}
-    for k, e in enumerate(_ORDER):
-        pts = _points(density)[e]
+    for k, e in enumerate(element_order(all_kernels.num_pes)):
+        pts = _points(density, all_kernels.num_pes)[e]
         if len(pts[0]) == 0:
             out[e] = pts
             continue
@@ -249,11 +253,12 @@ def new_element_point_selection(density, extra_points, IsSmallOld, IsSmall, MCPa
     prediction, and fresh extra points; an element that became small loses its points.  Returns (density, extra_points)."""
     if IsSmallOld == IsSmall:
         return density, extra_points
-    dens, extra = dict(_points(density)), dict(_points(extra_points))
+    order = element_order(all_kernels.num_pes)
+    dens, extra = dict(_points(density, all_kernels.num_pes)), dict(_points(extra_points, all_kernels.num_pes))
     NumPoints, NumExtraPoints = len(dens[(0, 0)][0]), len(extra[(0, 0)][0])
-    candidates = np.concatenate([np.asarray(x[e][0], dtype=float).reshape(-1, 2) for e in _ORDER for x in (dens, extra)])
+    candidates = np.concatenate([np.asarray(x[e][0], dtype=float).reshape(-1, 2) for e in order for x in (dens, extra)])
     seeds = _Seeds(int(rng.integers(1, 2 ** 62)))
-    for e in _ORDER:
+    for e in order:
         if IsSmallOld[e] and not IsSmall[e]:
             distribution = lambda r, e=e: new_point_predict(r, e[0], e[1], mass, dt, all_kernels, model, api)
             rho = distribution(candidates)
@@ -299,9 +304,11 @@ def main_tick(iTick, density, extra_points, IsSmall, MCParams, optimizer, all_ke
     IsSmall = is_very_small(density, mass, dt, all_kernels, model, api)
     opt_result = None
 
+    num_pes = all_kernels.num_pes
+
     def refit(params):
-        sets = K.construct_training_sets({e: v for e, v in density.items() if len(v[0])}, 2)
-        return K.TrainingKernels(params, sets, True, True, False, api=api, num_pes=2)
+        sets = K.construct_training_sets({e: v for e, v in density.items() if len(v[0])}, num_pes)
+        return K.TrainingKernels(params, sets, True, True, False, api=api, num_pes=num_pes)
 
     def reoptimise():
         nonlocal all_kernels, extra_points

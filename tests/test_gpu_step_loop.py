@@ -397,3 +397,39 @@ def test_three_level_tick_through_the_step_loop(gpu):
     assert set(d1) == set(dens) and all(len(d1[e][0]) == len(dens[e][0]) and len(x1[e][0]) == len(extra[e][0]) for e in dens)
     assert abs(k1.calculate_population() - pop0) <= 0.05 * abs(pop0)
     assert abs(k1.calculate_purity() - pur0) <= 0.10 * abs(pur0)
+
+
+def test_three_level_main_tick_with_elements_appearing(gpu):
+    """steploop.main_tick for a three-level system (the reference's loop of main.cpp:136-186 compiled for NumPES = 3, where it asserts): all
+    population on the lowest state just before the three-state crossing of the library's model; is_very_small asks the N-level new-point
+    prediction for the five empty elements, elements that stopped being negligible get their points by the Metropolis re-selection, the
+    optimiser (six-element parameter layout) runs because the element set changed, and the refitted kernels keep the population"""
+    from gaussian_process_liouville_equation_amd import optimization as O, steploop as S
+    rng = np.random.default_rng(5)
+    sig, x0, p0 = np.array([0.7086, 0.7056]), -0.6, 14.112
+    wig = lambda r: np.exp(-0.5 * (((r - [x0, p0]) / sig) ** 2).sum(axis=1)) / (2 * np.pi * sig.prod())
+    r, re = rng.normal(size=(100, 2)) * sig + [x0, p0], rng.normal(size=(200, 2)) * sig + [x0, p0]
+    empty = (np.zeros((0, 2)), np.zeros(0, dtype=complex))
+    order = K.element_order(3)
+    dens = {e: empty for e in order}
+    extra = {e: empty for e in order}
+    dens[(0, 0)], extra[(0, 0)] = (r, wig(r).astype(complex)), (re, wig(re).astype(complex))
+    e0 = O.calculate_total_energy_average_one_surface(dens[(0, 0)], MASS, 0)
+    opt = O.Optimization(sig, (x0 - 5, p0 - 5), (x0 + 5, p0 + 5), MASS, e0, 1.0, api=gpu, num_pes=3, local_maxeval=40, searches="native")
+    opt.optimize({(0, 0): dens[(0, 0)]}, {(0, 0): extra[(0, 0)]})
+    k0 = K.TrainingKernels(opt.get_parameters(), K.construct_training_sets({(0, 0): dens[(0, 0)]}, 3), True, True, False, api=gpu, num_pes=3)
+    assert k0.num_pes == 3 and abs(k0.calculate_population() - 1.0) < 0.05
+    small0 = {e: e != (0, 0) for e in order}
+    # the new-point prediction of the coupled elements at the packet: population flows to the neighbouring state through the coherence
+    np10 = S.new_point_predict(r[:20], 1, 0, MASS, DT, k0, S.TSAC, gpu)
+    np22 = S.new_point_predict(r[:20], 2, 2, MASS, DT, k0, S.TSAC, gpu)
+    assert np.abs(np10).max() > 1e-5 and np.abs(np10).max() > 10 * np.abs(np22).max()  # 0 -> 1 is first order in the coupling, 0 -> 2 second
+    small = S.is_very_small(dens, MASS, DT, k0, S.TSAC, gpu)
+    assert set(small) == set(order) and small[(0, 0)] is False and small[(1, 0)] is False
+    mc = {e: S.MCParameters(20, 0.3) for e in order}
+    d1, x1, s1, k1, res1 = S.main_tick(1, dens, extra, small0, mc, opt, k0, MASS, DT, 50, 200, 1.0, rng, S.TSAC, gpu)
+    assert res1 is not None and s1 == small                      # the element set changed: re-selection + optimisation (main.cpp:148-163)
+    assert len(d1[(1, 0)][0]) == 100 and len(x1[(1, 0)][0]) == 200  # the coherence with the neighbouring state now has its points
+    for e in order:
+        assert (len(d1[e][0]) == 0) == s1[e]
+    assert abs(k1.calculate_population() - 1.0) < 0.1 and k1.num_pes == 3
