@@ -213,3 +213,25 @@ def test_optimization_adapter_runs_the_reference_tiers(gpu, coherence):
         assert abs(got["energy"][0] / got["energy"][1] - 1.0) < 0.05
         assert abs(got["purity"][0] / got["purity"][1] - 1.0) < 0.05
     assert np.isfinite(got["reopt_error"][0]) and got["reopt_type"][0] in (1, 2, 3)
+
+
+def test_adapters_compiled_for_three_levels(gpu):
+    """tests/cpp/dropin_callers.cpp compiled with NumPES = 3 (as stdafx.h:111 would be): TrainingKernels over six elements, the point-wise lambda,
+    and the tick's three calls — evolve(density, ...), evolve(extra, ...), is_very_small(...) — which at three levels go to gple_evolve_n where the
+    reference asserts (evolve.cpp:367-371).  Checked here: it runs, every populated element keeps its points with finite densities, the last diagonal
+    element (left empty by the driver) stays empty, and the aggregates are those of five populated elements."""
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_callers_3pes")
+    if not os.path.exists(exe):
+        pytest.fail("tests/cpp/dropin_callers_3pes missing: run __graft_entry__.build()")
+    N = 40
+    out = subprocess.run([exe, str(N)], check=True, capture_output=True, text=True, timeout=300).stdout
+    got = {}
+    for line in out.strip().splitlines():
+        key, *vals = line.split()
+        got[key] = np.array([float(v) for v in vals]) if key != "phase_first" else vals
+    for e in ("00", "10", "11", "20", "21"):
+        line = got[f"evolve_{e}"].reshape(-1, 4)
+        assert len(line) == N and np.all(np.isfinite(line))
+    assert len(got["evolve_22"]) == 0
+    assert np.isfinite(got["all_population"][0]) and got["all_population"][0] > 0 and np.isfinite(got["all_purity"][0])
+    assert got["threads_same"][0] == 1 and got["threads_same"][1] == 1
