@@ -159,6 +159,8 @@ def make_rccl_comm(torch, dist, rank, world):
     bytes travel over torch.distributed's control group, every rank joins with ncclCommInitRank on its current device.  librccl is loaded
     RTLD_GLOBAL — torch's own copy when it ships one, so that the process holds ONE RCCL — and libgple_hip.so finds ncclAllGather in the
     process image, i.e. in the library this communicator belongs to."""
+    if os.environ.get("BENCH_FORCE_COMM_FAIL"):  # rehearsal of the fallback
+        raise RuntimeError("BENCH_FORCE_COMM_FAIL is set")
     cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"]
     path = next((q for q in cands if os.path.exists(q)), "librccl.so.1")
     rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)
@@ -181,6 +183,27 @@ def make_rccl_comm(torch, dist, rank, world):
         raise RuntimeError(f"ncclCommInitRank(rank {rank} of {world}): {rccl.ncclGetErrorString(rc).decode()}")
     _RCCL["lib"] = rccl
     return comm, path
+
+
+def try_rccl_comm(torch, dist, rank, world):
+    """make_rccl_comm, or (None, path, reason) on EVERY rank when it failed on any (the ranks agree over the control group): the caller then
+    falls back to torch.distributed's own RCCL group and says so in the JSON line — a scaling run that dies in communicator setup measures nothing."""
+    comm, path, why = None, None, ""
+    try:
+        comm, path = make_rccl_comm(torch, dist, rank, world)
+    except Exception as e:  # noqa: BLE001 - anything: missing library, symbol, ncclCommInitRank error
+        why = f"rank {rank}: {type(e).__name__}: {e}"
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+    if world > 1:
+        if dist.get_backend() == "nccl":
+            ok = ok.cuda()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if comm is not None:
+            destroy_rccl_comm(comm)
+        sys.stderr.write(f"bench.py: the library-side RCCL communicator could not be created ({why or 'on another rank'}); falling back to torch.distributed\n")
+        return None, path, why or "failed on another rank"
+    return comm, path, ""
 
 
 def destroy_rccl_comm(comm):
@@ -308,7 +331,15 @@ def main():
         make_rccl_comm(torch, dist, rank, world)
     comm, via_note = None, ("torch.distributed all_gather_into_tensor" if world > 1 else "no collective (one rank)")
     if capi:
-        comm, rccl_path = make_rccl_comm(torch, dist, rank, world)
+        comm, rccl_path, why = try_rccl_comm(torch, dist, rank, world)
+        if comm is None:  # every rank agrees: the A/B path on torch.distributed's own RCCL group, named as a fallback in the line
+            capi, args.via = False, "torch"
+            group = dist.new_group(backend="nccl") if world > 1 else None
+            shard = parallel.GridShardedStep(M, rows, alloc, group=group, shard=not by_element, cyclic=args.prune and not cplx)
+            lo, hi = shard.lo, shard.hi
+            dgrid_mine = dgrid_all[shard.idx.to(dgrid_all.device)].contiguous() if shard.cyclic else None
+            via_note = f"FALLBACK: torch.distributed all_gather_into_tensor over its own RCCL group (the library-side communicator failed: {why})"
+    if capi:
         via_note = f"gple_{'complex' if cplx else 'real'}_predict_sharded: ncclAllGather inside the library ({rccl_path}), block-cyclic deal of 128-point blocks"
         full_out = torch.empty(rows, M, dtype=torch.float64, device="cuda")
         pts_mine, _ = parallel.deal_shares(M, [1] * world)
@@ -513,7 +544,12 @@ def elements_step(args, pkg, c, parallel, torch, dist, rank, world, dev):
                      "sc": c.ComplexFitScalars() if cplx else c.RealFitScalars()})
     dgrid = torch.from_numpy(grid).cuda()
     capi = args.via == "capi"
-    comm, rccl_path = (make_rccl_comm(torch, dist, rank, world) if (capi and (world > 1 or args.comm_at_one)) else (None, None))
+    comm, rccl_path, torch_group, fallback = None, None, None, ""
+    if capi and (world > 1 or args.comm_at_one):
+        comm, rccl_path, fallback = try_rccl_comm(torch, dist, rank, world)
+        if comm is None:  # every rank agrees: gather_dealt over torch.distributed's own RCCL group instead, named as a fallback in the line
+            capi, args.via = False, "torch"
+            torch_group = dist.new_group(backend="nccl") if world > 1 else None
     flags = c.CALC_ERROR | c.CALC_AVERAGE | c.IO_DEVICE
     predict_flag = 0 if args.prune else c.PREDICT_FULL
 
@@ -556,7 +592,7 @@ def elements_step(args, pkg, c, parallel, torch, dist, rank, world, dev):
             local[0:ow, :n] = t_mean.view(n, ow).t()
             local[ow, :n] = t_var
             local[ow + 1:, :n] = t_cut.view(n, ow).t()
-        full = parallel.gather_dealt(local, M, weights, via_host=args.backend == "gloo")
+        full = parallel.gather_dealt(local, M, weights, group=torch_group, via_host=args.backend == "gloo")
         out[0:ow].view(-1).view(M, ow).copy_(full[0:ow].t())
         out[ow].copy_(full[ow])
         out[ow + 1:].view(-1).view(M, ow).copy_(full[ow + 1:].t())
@@ -625,7 +661,8 @@ def elements_step(args, pkg, c, parallel, torch, dist, rank, world, dev):
                                + (" [--prune: far rows not contracted]" if args.prune else ""),
                    "N": N, "M": M, "elements": kinds, "parallelism": "single GPU, elements in turn" if world == 1 else f"{world} ranks, plan '{plan.name}'",
                    "via": args.via, "collective": (f"gple_*_predict_dealt: ncclAllGather inside the library ({rccl_path}), weighted block deal" if comm is not None
-                                                   else ("none (one rank)" if world == 1 else "torch.distributed all_gather_into_tensor")),
+                                                   else ("none (one rank)" if world == 1 else "torch.distributed all_gather_into_tensor"
+                                                         + (f" — FALLBACK, the library-side communicator failed: {fallback}" if fallback else ""))),
                    "plan": plan.describe()},
         "roofline": {"bound": "mfma", "kernel": "rownorm2_kernel<4,4,false> (fp64 MFMA triangular contraction ||T k*||^2), all elements of this rank",
                      "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": None,
