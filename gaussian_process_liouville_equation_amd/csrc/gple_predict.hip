@@ -597,6 +597,128 @@ namespace gple
 		}
 
 
+		// ---- the same contraction for SHORT factors (n <= 512: one or two N-tiles) and few row blocks — C1: N = 256, 128 x 128 grid ----------
+		// rownorm2_kernel<2,8> gives such a launch 128 workgroups of 16 k-steps for 256 CUs, and every step waits for its slab's DMA round trip
+		// (~2.5 us against ~1 us of MFMA work in the diagonal tile): 47 us for 1.1 GFLOP, 0.29 of the peak.  Here a workgroup takes 64 rows (twice
+		// the workgroups) and keeps THREE slabs in flight (a slab is requested two steps ahead; 64-row slabs make three stages fit: 3 x 43 KB),
+		// so a step waits for a DMA issued two steps ago.  The per-row arithmetic is that of <2,8> — one 16-row fragment per wave against the same
+		// 8 interleaved column blocks, the same k order, the same order of the partial sums — so a row's q has the same bits whichever of the
+		// two kernels a launch gets (test_short_factor_kernel_has_the_bits_of_the_general_one).
+		// A slab in LDS: 1 KB chunks (what one wave instruction of the LDS-DMA fills: lanes 0-31 one k-row of 64 doubles, lanes 32-63 another),
+		// chunk stride 144 doubles; k-row k sits in chunk 2 (k / 4) + (k & 1), half (k >> 1) & 1: the four k-rows of a fragment read then fall on
+		// disjoint bank halves in each of the instruction's two passes, as with the 128-row layout.
+		template <int WNI>
+		__device__ __forceinline__ void rownorm3_tiles(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt, int n_total, double* lds,
+			double& rsq, int m0, int wm, int vg)
+		{
+			constexpr int KB = 16, NT = NTHREADS, BF = 8, WN = 2, NST = 3; // 64 rows per workgroup
+			constexpr int ACH = 144;              // chunk stride of the A slab (doubles)
+			constexpr int ASL = (KB / 2) * ACH;   // 8 chunks per slab
+			constexpr int BSL = KB * BS;
+			constexpr int NBv = BN * KB / 2 / NT; // B: 4 wave instructions per wave and slab; A: one
+			double* const As = lds;
+			double* const Bs = lds + NST * ASL;
+			const int t = threadIdx.x, lane = t & 63;
+			const int fk = lane >> 4, fr = lane & 15;
+			const int ntiles = n_total / BN;
+			const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+			auto lds_addr = [](const double* p) { return static_cast<unsigned>(reinterpret_cast<unsigned long>((__attribute__((address_space(3))) const double*)p)); };
+			auto glds16 = [](const double* gsrc, unsigned lds_dst) {
+				unsigned keep;
+				asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+							 : "=&s"(keep)
+							 : "v"(gsrc), "s"(lds_dst)
+							 : "memory");
+			};
+			const unsigned As_addr = lds_addr(As), Bs_addr = lds_addr(Bs);
+			// A: wave w fills chunk w of the slab: k-rows ka = 4 (w / 2) + (w & 1) (lanes 0-31) and ka + 2 (lanes 32-63)
+			const int ka = 4 * (w >> 1) + (w & 1) + 2 * (lane >> 5);
+			auto stage_ab = [&](int n0, int k0, int buf) {
+				glds16(Ks + m0 + static_cast<long>(k0 + ka) * rows + 2 * (lane & 31), As_addr + 8u * static_cast<unsigned>(buf * ASL + w * ACH));
+				const double* __restrict__ bbase = T + n0 + static_cast<long>(k0) * ldt + 128 * (w & 1) + 2 * lane;
+#pragma unroll
+				for (int qq = 0; qq < NBv; ++qq)
+				{
+					const int k = (w >> 1) + (NT / 128) * qq;
+					glds16(bbase + static_cast<long>(k) * ldt, Bs_addr + 8u * static_cast<unsigned>(buf * BSL + k * BS + 128 * (w & 1)));
+				}
+			};
+			// k-row (kk + fk) of the A slab, row fragment of this wave
+			auto a_at = [&](const double* slab, int k) { return slab[(2 * (k >> 2) + (k & 1)) * ACH + ((k >> 1) & 1) * 64 + wm * 16 + fr]; };
+			for (int jt = 0; jt < ntiles; ++jt)
+			{
+				if (snake(jt, VG) != vg) continue; // uniform; no accumulator is live here
+				const int n0 = jt * BN;
+				const int nk = (n0 + BN) / KB; // >= 16
+				d4 acc[BF];
+#pragma unroll
+				for (int j = 0; j < BF; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+				__syncthreads();
+				stage_ab(n0, 0, 0);
+				stage_ab(n0, KB, 1);
+				asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); // slab 0 has landed (the 5 requests of slab 1 may still be out)
+				auto kstep = [&](auto tmin_tag, int s) {
+					constexpr int TMIN = decltype(tmin_tag)::value;
+					const double* __restrict__ pa = As + (s % NST) * ASL;
+					const double* __restrict__ pb = Bs + (s % NST) * BSL + WNI * 16 + fr;
+					// slab s + 2 goes into the buffer step s - 1 read (every wave is past the barrier that ended it)
+					if (s + 2 < nk) stage_ab(n0, (s + 2) * KB, (s + 2) % NST);
+#pragma unroll
+					for (int kk = 0; kk < KB; kk += 4)
+					{
+						const double af = a_at(pa, kk + fk);
+						double bf[BF];
+#pragma unroll
+						for (int j = TMIN; j < BF; ++j) bf[j] = pb[(kk + fk) * BS + j * (16 * WN)];
+#pragma unroll
+						for (int j = TMIN; j < BF; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af, acc[j], 0, 0, 0);
+					}
+					// the next step reads slab s + 1: everything but the requests of slab s + 2 (if any were made) must have landed
+					if (s + 2 < nk) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+					else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+				};
+				const int nd = n0 / KB;
+				for (int s = 0; s < nd; ++s) kstep(std::integral_constant<int, 0>{}, s);
+				[&]<int... D>(std::integer_sequence<int, D...>) {
+					(kstep(std::integral_constant<int, (D > WNI ? (D - WNI + WN - 1) / WN : 0)>{}, nd + D), ...);
+				}(std::make_integer_sequence<int, BN / KB>{});
+#pragma unroll
+				for (int j = 0; j < BF; ++j)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) rsq = fma(acc[j][r], acc[j][r], rsq);
+			}
+		}
+		__global__ void __launch_bounds__(NTHREADS, 1) rownorm3_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt, int n_total,
+			double* __restrict__ q, long qstride)
+		{
+			constexpr int KB = 16, TM = 64, WN = 2, NST = 3;
+			__shared__ __attribute__((aligned(16))) double lds[NST * (KB / 2) * 144 + NST * KB * BS];
+			const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int wm = w / WN, wn = w % WN;
+			const int m0 = blockIdx.x * TM, g = blockIdx.y, G = gridDim.y;
+			for (int vg = 0; vg < VG; ++vg)
+			{
+				if (snake(vg, G) != g) continue; // uniform
+				double rsq = 0.0;
+				if (wn == 0) rownorm3_tiles<0>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm, vg);
+				else rownorm3_tiles<1>(Ks, rows, T, ldt, n_total, lds, rsq, m0, wm, vg);
+				__syncthreads();
+				double v = rsq;
+				v += __shfl_xor(v, 16);
+				v += __shfl_xor(v, 32);
+				if (lane < 16) lds[wn * TM + wm * 16 + lane] = v;
+				__syncthreads();
+				if (threadIdx.x < TM)
+				{
+					double sum = 0.0;
+#pragma unroll
+					for (int c = 0; c < WN; ++c) sum += lds[c * TM + threadIdx.x];
+					q[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = sum;
+				}
+				__syncthreads();
+			}
+		}
+
 		// ---- a handful of test points (the one-point predicts of main.cpp:75-101, evolve.cpp:298, mc.cpp:158-172) --------------
 		// For M <= FEW_MAX typed rows the tiled paths pad to 128 rows, materialise K* and run a GEMM against all of T: 0.1-0.65 ms
 		// per call, almost all of it launches, padding and copies.  Here the contraction is a triangular mat-vec per point with K*
@@ -868,6 +990,12 @@ namespace gple
 			return e ? atoi(e) : -1;
 		}();
 		const int variant = forced >= 0 ? forced : (a.n_total / BN >= 8 ? 2 : 3); // with the LDS-DMA staging the 2 x 8 blocking leads below eight N-tiles (C2: 64.3 vs 62.9 / 61.2 TFLOP/s)
+		// short factors with few row blocks (C1): 64-row workgroups with three slabs in flight (rownorm3_kernel; same bits as <2,8>).  GPLE_ROWNORM_SHORT=0: A/B
+		static const bool short_ok = [] {
+			const char* e = getenv("GPLE_ROWNORM_SHORT");
+			return e == nullptr || atoi(e) != 0;
+		}();
+		const bool short_factor = short_ok && variant == 3 && a.n_total / BN <= 2 && a.m_rows / BM <= 2 * device_cu_count();
 		double* Ks = scratch;
 		double* mu_part = scratch + static_cast<size_t>(chunk_rows) * a.n_total;
 		const bool small = few_rows && chunk_rows == a.m_rows;
@@ -976,6 +1104,8 @@ namespace gple
 					if (e != hipSuccess) return e;
 					hipLaunchKernelGGL(colsumsq_kernel, dim3(rows), dim3(256), 0, s, Z, static_cast<long>(a.n_total), a.n_total, a.q + row0);
 				}
+				else if (short_factor)
+					hipLaunchKernelGGL(rownorm3_kernel, dim3(rows / 64, split), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows));
 				else
 					launch_rownorm(false, dim3(rows / BM, split), rows, qpart + row0, Prune{});
 				chunk_timer_stop(ctx);

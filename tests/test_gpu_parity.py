@@ -575,3 +575,21 @@ def test_predict_skips_what_nobody_consumes(gpu, cplx):
             kss = theta[0] ** 2 * ((theta[1] ** 2 + theta[4] ** 2 + theta[7] ** 2) if cplx else (1 + theta[3] ** 2))
             assert 0.15 < (mu2 >= 4 * kss).mean() < 0.85
     fit.release()
+
+
+@pytest.mark.parametrize("N", [200, 256, 400])
+def test_short_factor_kernel_has_the_bits_of_the_general_one(gpu, N):
+    """n <= 512 with few row blocks (C1) runs on rownorm3_kernel (64-row workgroups, three slabs in flight); the same rows inside a call large
+    enough for the general kernel (rownorm2_kernel<2,8>) must come out bit for bit — the per-row arithmetic is the same by construction"""
+    from tests.test_gpu_configs import config_inputs, THETA_R
+    X, y, grid, _ = config_inputs(N, 128, 5)
+    fit = gpu.real_fit(THETA_R, X, y, 0)
+    rng = np.random.default_rng(N)
+    pts = X[rng.integers(0, N, 16384)] + rng.normal(0, 0.3, (16384, 2))
+    a = gpu.real_predict(fit, pts, flags=c.PREDICT_FULL)
+    more = np.concatenate([pts, X[rng.integers(0, N, 4 * 16384 + 300)] + rng.normal(0, 0.5, (4 * 16384 + 300, 2))])
+    b = gpu.real_predict(fit, more, flags=c.PREDICT_FULL)
+    for k in ("prediction", "variance", "cutoff"):
+        assert np.array_equal(a[k], b[k][:16384]), k
+    assert a["variance"].min() >= -1e-9 and (a["variance"] < 0.5).any()
+    fit.release()
