@@ -225,7 +225,8 @@ int gple_objective_eval(gple_objective* objective, const double* x, size_t n, do
  * `part` of `nparts` forms the N^3 derivative products of the parameters ip with ip % nparts == part (the cheap first and last parameters on
  * part 0), predicts its contiguous share of the extra points, and returns its partial value and gradient.  The sum over the parts (one
  * all-reduce of n + 1 doubles) is gple_objective_eval's value and gradient up to the rounding of that sum; make_normal (opt.cpp:420-431:
- * NaN / Inf -> DBL_MAX) is applied by the caller AFTER the sum.  nparts == 1 is gple_objective_eval. */
+ * NaN / Inf -> DBL_MAX) is applied by the caller AFTER the sum.  nparts == 1 is gple_objective_eval.  One evaluation at a time per context
+ * (the parameter split is a state of the context for the duration of the call). */
 int gple_objective_eval_part(gple_objective* objective, const double* x, size_t n, int part, int nparts, double* value, double* grad);
 int gple_objective_release(gple_objective* objective);
 

@@ -1,5 +1,7 @@
 """GPU (MI355X): the HIP path, called through the C-ABI, against the 50-digit fixtures, the CPU oracle and
 size-independent identities at BASELINE.json's full sizes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -593,3 +595,36 @@ def test_short_factor_kernel_has_the_bits_of_the_general_one(gpu, N):
         assert np.array_equal(a[k], b[k][:16384]), k
     assert a["variance"].min() >= -1e-9 and (a["variance"] < 0.5).any()
     fit.release()
+
+
+def test_forced_128_tiles_on_odd_fork_points_stay_off_unwritten_blocks():
+    """the block-row inverse runs its triangular GEMMs on sub-matrices whose origin is a fork point — a multiple of 64 only.  A
+    128-tile with a triangular k-range starts at its 128-aligned diagonal tile and would take in a block above the diagonal that nobody writes
+    when the origin is an odd multiple of 64.  Own process (the knobs are read once): 128-tiles forced for triangular work, one fork at 55 %
+    of n = 2304 (column 1216 = 19 x 64), T and the Cholesky workspace poisoned with NaN — the fit's identities must hold."""
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import gaussian_process_liouville_equation_amd as pkg
+from gaussian_process_liouville_equation_amd import _capi as c
+from tests import parity
+api = pkg.open_api(0)
+for N in (2100, 2304, 3000):
+    X, y, Xs = parity.synthetic_real(N, 500, 20240607 + N)
+    theta = [1.0, 0.7086, 0.7056, 1e-2]
+    fit = api.real_fit(theta, X, y, 3)
+    assert fit.scalars["info"] == 0 and np.isfinite(fit.scalars["error"])
+    K, W, v, ys = fit.get(c.R_KERNEL), fit.get(c.R_INVERSE), fit.get(c.R_INVLBL), fit.get(c.R_LABEL)
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    assert np.all(np.isfinite(W)) and n1(K @ W - np.eye(N)) <= 50 * N * parity.EPS * n1(K) * n1(W)
+    assert np.abs(K @ v - ys).max() <= 50 * N * parity.EPS * (n1(K) * np.abs(v).max() + np.abs(ys).max())
+    p = api.real_predict(fit, Xs)
+    assert np.all(np.isfinite(p["variance"])) and p["variance"].min() >= -1e-7
+print("ok")
+''' % ROOT
+    env = dict(os.environ, GPLE_POISON_T="1", GPLE_CHOL_FORKS="55", GPLE_GEMM_128_MIN_TILES_TRI="1", GPLE_GEMM_SPLITK_MAX_TILES="0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
