@@ -143,6 +143,7 @@ static void ctx_drop(gple_ctx* ctx)
 	for (auto& e : ctx->pool) (void)hipFree(e.p);
 	if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
 	if (ctx->prune_stats) (void)hipFree(ctx->prune_stats);
+	if (ctx->dag_flags) (void)hipFree(ctx->dag_flags);
 	timer_collect(ctx);
 	for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
 	if (ctx->side_stream)

@@ -9,10 +9,12 @@
 // NaN which propagates into every output, and *info records the first offending column (reference behaviour:
 // LDLT::info() is never checked, NaN/Inf are clamped later by opt.cpp:420-431).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <map>
 #include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -760,6 +762,484 @@ namespace gple
 			stamp();
 		}
 
+		// ---- the panels of an outer block without a launch between them -------------------------------------------------------------
+		// One launch per panel costs the spine of the factorisation ~16 us per 64 columns, of which the dependency chain itself (the four
+		// 16-column chains, the updates between them, the last 16 x 16 inverse) is ~9: the rest is the launch, reloading what the previous
+		// launch had in LDS, and waiting for the slowest workgroup of the panel before the next panel may start.  Here a whole range of
+		// panels is ONE launch.  Workgroup 0 (the spine) walks down the diagonal and never waits for the panel rows below it; everything else
+		// is done by single waves (four per workgroup, no LDS, no barrier) that own a 16-row quarter of one 64 x 64 tile at a time,
+		// left-looking:
+		//   tile (r, c), c <= r - 2 or r outside the outer block:   L(r, c) = (A(r, c) - sum_{i < c} L(r, i) L(c, i)^T) T_c^T    after T_c is out
+		//   tiles (r, r - 1) and (r, r) of a row the spine will reach: A~ = A - sum_{i <= r - 2} L(r, i) L(., i)^T, stored in place ("pre" tasks);
+		//   the spine finishes them itself: L(k, k - 1) = A~(k, k - 1) T_{k-1}^T with T_{k-1} still in its LDS, A_kk = A~(k, k) - L(k, k - 1) L(k, k - 1)^T,
+		//   so that no other workgroup sits between T_{k-1} and the first chain of panel k.
+		// Hand-over is by flags in global memory, one int per tile quarter (= epoch of the fit that made it final; the buffer is never
+		// cleared), data and flags as agent-scope relaxed atomics (sc1: write-through stores, loads that do not trust another XCD's L2) with
+		// s_waitcnt vmcnt(0) between a quarter's stores and its flag (probes/hop_probe.hip: 1.9 us per hand-over of a tile, 0.55 for a flag alone).
+		// Tasks are dealt round-robin to the waves in an order in which every task depends on earlier ones only (column by column, the rows the
+		// spine needs next first), so with every workgroup resident — the grid never exceeds one per CU — the first unfinished task can always run.
+		// Every wait is bounded: after DAG_POLL_LIMIT polls a wave raises the error flag, everybody leaves, and *info becomes -1.
+		constexpr int DAG_POLL_LIMIT = 1 << 21;
+		struct DagArgs
+		{
+			double* A;
+			long lda;
+			double* T;
+			long ldt;
+			int* info;
+			double* uvec;
+			int* flags; // 4 ints per tile (r * FS + c), then per column: T_k, pre-tile (k, k - 1), pre-tile (k, k); then the error word (4 ints in front: the ticket counter)
+			int FS, R;  // block columns of the matrix; block rows of A (one more than FS with the label row)
+			int c0, C1; // the panels of this launch, an outer block of the factorisation: sums start at c0, rows below C1 are spine rows
+			int epoch, nunits, seq; // units of work (tiles: four quarter tasks each); number of this launch within the factorisation
+			long long* stamps; // probe (GPLE_CHOL_DAG_STAMPS): 8 wall-clock stamps per panel of the spine, or nullptr
+		};
+		__device__ __forceinline__ double ldc(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		__device__ __forceinline__ void stc(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		__device__ __forceinline__ int ldf(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		__device__ __forceinline__ void stf(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		__device__ __forceinline__ int* dag_tile(const DagArgs& a, int r, int c) { return a.flags + 4 * (static_cast<long>(r) * a.FS + c); }
+		__device__ __forceinline__ int* dag_t(const DagArgs& a, int k) { return a.flags + 4 * (static_cast<long>(a.R) * a.FS + k); }
+		__device__ __forceinline__ int* dag_pb(const DagArgs& a, int k) { return a.flags + 4 * (static_cast<long>(a.R + 1) * a.FS + k); }
+		__device__ __forceinline__ int* dag_pc(const DagArgs& a, int k) { return a.flags + 4 * (static_cast<long>(a.R + 2) * a.FS + k); }
+		__device__ __forceinline__ int* dag_err(const DagArgs& a) { return a.flags + 4 * static_cast<long>(a.R + 3) * a.FS; }
+		// the ticket counter of the work queue: in front of the flags, at the same place whatever the matrix size — its high word outgrows every epoch
+		// and must never be read as a flag
+		__device__ __forceinline__ unsigned long long* dag_tickets(const DagArgs& a) { return reinterpret_cast<unsigned long long*>(a.flags - 4); }
+		// the whole wave waits until the four quarter flags at f4 and (if given) the four at g4 and the single flag at f1 carry this epoch
+		__device__ __forceinline__ bool dag_wait(const DagArgs& a, const int* f4, const int* g4, const int* f1, int lane)
+		{
+			const int* p = f4 + (lane & 3);
+			if (g4 != nullptr && (lane & 4)) p = g4 + (lane & 3);
+			if (f1 != nullptr && lane >= 8) p = f1;
+			const int* const err = dag_err(a);
+			for (int it = 0; it < DAG_POLL_LIMIT; ++it)
+			{
+				const int v = ldf(p);
+				if (__all(v - a.epoch >= 0))
+				{
+					asm volatile("" ::: "memory");
+					return true;
+				}
+				if ((it & 31) == 31 && ldf(err) - a.epoch >= 0) return false;
+				__builtin_amdgcn_s_sleep(2);
+			}
+			if (lane == 0) stf(dag_err(a), a.epoch), atomicExch(a.info, -1);
+			return false;
+		}
+		// one worker task: quarter qa (rows 16 qa ..) of tile (r, cs); sums over i in [c0, iend) of L(r, i) L(xr, i)^T are taken off, then
+		// (fin) the result is multiplied by T_cs^T; stored in place; *done = epoch.  Accumulator element acc[b][q] of lane (fr, fk) is entry
+		// (row 16 qa + fr, column 16 b + fk + 4 q) of the tile — also the layout of the MFMA operand "row fr, k = 4 (4 b + q) + fk", so the
+		// product with T_cs^T needs no transposition.
+		__device__ __forceinline__ bool dag_task(const DagArgs& a, int r, int xr, int cs, int iend, bool fin, int qa, int* done, int lane)
+		{
+			const int fr = lane & 15, fk = lane >> 4;
+			const long lda = a.lda;
+			double* const Ct = a.A + static_cast<long>(r) * NB + static_cast<long>(cs) * NB * lda + 16 * qa + fr;
+			d4v acc[4];
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) acc[b][q] = Ct[static_cast<long>(16 * b + fk + 4 * q) * lda]; // as the previous launches left it
+			for (int i = a.c0; i < iend; ++i)
+			{
+				if (!dag_wait(a, dag_tile(a, xr, i), nullptr, dag_tile(a, r, i) + qa, lane)) return false;
+				const double* const Ly = a.A + static_cast<long>(r) * NB + static_cast<long>(i) * NB * lda + 16 * qa + fr;
+				const double* const Lx = a.A + static_cast<long>(xr) * NB + static_cast<long>(i) * NB * lda + fr;
+				// four chunks of 16 columns, the next one requested before the current one is multiplied (two operand sets of 40 registers)
+				double y[2][4], x[2][4][4];
+				auto fetch = [&](int ch, int buf) {
+#pragma unroll
+					for (int q = 0; q < 4; ++q)
+					{
+						const long kcol = static_cast<long>(16 * ch + 4 * q + fk) * lda;
+						y[buf][q] = ldc(Ly + kcol);
+#pragma unroll
+						for (int b = 0; b < 4; ++b) x[buf][b][q] = ldc(Lx + 16 * b + kcol);
+					}
+				};
+				fetch(0, 0);
+#pragma unroll
+				for (int ch = 0; ch < 4; ++ch)
+				{
+					if (ch + 1 < 4) fetch(ch + 1, (ch + 1) & 1);
+#pragma unroll
+					for (int q = 0; q < 4; ++q)
+#pragma unroll
+						for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ch & 1][b][q], y[ch & 1][q], acc[b], 0, 0, 0);
+				}
+			}
+			if (fin)
+			{
+				if (!dag_wait(a, dag_t(a, cs), nullptr, nullptr, lane)) return false;
+				const double* const Tt = a.T + static_cast<long>(cs) * NB * (a.ldt + 1) + fr;
+				double xt[40];
+				[&]<int... Bs>(std::integer_sequence<int, Bs...>)
+				{
+					(
+						[&] {
+							constexpr int b = Bs, off = 2 * b * (b + 1); // 4 + 8 + .. fragments before block row b
+#pragma unroll
+							for (int q = 0; q < 4 * (b + 1); ++q) xt[off + q] = ldc(Tt + 16 * b + static_cast<long>(4 * q + fk) * a.ldt);
+						}(),
+						...);
+				}
+				(std::make_integer_sequence<int, 4>{});
+				d4v out[4];
+				[&]<int... Bs>(std::integer_sequence<int, Bs...>)
+				{
+					(
+						[&] {
+							constexpr int b = Bs, off = 2 * b * (b + 1);
+							out[b] = (d4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+							for (int q = 0; q < 4 * (b + 1); ++q) out[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[off + q], acc[q >> 2][q & 3], out[b], 0, 0, 0);
+						}(),
+						...);
+				}
+				(std::make_integer_sequence<int, 4>{});
+#pragma unroll
+				for (int b = 0; b < 4; ++b) acc[b] = out[b];
+				// the label row below the matrix: its factor entries are u = L^-1 y
+				if (a.uvec != nullptr && r == a.R - 1 && qa == 0 && fr == 0)
+#pragma unroll
+					for (int b = 0; b < 4; ++b)
+#pragma unroll
+						for (int q = 0; q < 4; ++q) a.uvec[cs * NB + 16 * b + fk + 4 * q] = acc[b][q];
+			}
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) stc(Ct + static_cast<long>(16 * b + fk + 4 * q) * lda, acc[b][q]);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (lane == 0) stf(done, a.epoch);
+			return true;
+		}
+		// tasks of the launch, in dependency order; host and device count them the same way.  Column c of the block [c0, C1): the tiles below
+		// row c + 1 (the spine finishes (c + 1, c) itself), with the two pre-tiles of row c + 2 right after tile (c + 2, c), which they need
+		__host__ __device__ inline int dag_column_units(int c, int C1, int R, bool& has_pre, int& lo)
+		{
+			lo = c + 1 < C1 ? c + 2 : c + 1;
+			has_pre = c + 2 < C1;
+			const int ng = R - lo > 0 ? R - lo : 0;
+			return ng + (has_pre ? 2 : 0);
+		}
+		__host__ inline int dag_count_units(int c0, int C1, int R)
+		{
+			int n = 0;
+			for (int c = c0; c < C1; ++c)
+			{
+				bool hp;
+				int lo;
+				n += dag_column_units(c, C1, R, hp, lo);
+			}
+			return n;
+		}
+
+		__global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a)
+		{
+			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+			if (blockIdx.x != 0)
+			{
+				// Units are handed out in their dependency order from one counter: whatever a unit waits for was handed out before it, to a workgroup
+				// that is running, so the launch makes progress with any number of its workgroups resident (workgroup 0, dispatched first, is
+				// the spine).  The counter is never cleared: every launch raises it to its own floor (epoch, launch number) before drawing.
+				__shared__ int cur_unit;
+				const unsigned long long floor = (static_cast<unsigned long long>(a.epoch) * 64ull + static_cast<unsigned long long>(a.seq)) << 32;
+				for (;;)
+				{
+					if (t == 0)
+					{
+						atomicMax(dag_tickets(a), floor);
+						cur_unit = static_cast<int>(atomicAdd(dag_tickets(a), 1ull) - floor);
+					}
+					__syncthreads();
+					int u = cur_unit;
+					__syncthreads();
+					if (u >= a.nunits) return;
+					const int qa = w;
+					// kind 0: tile (r, c) to the end; 1: pre-tile (r, r - 1); 2: pre-tile (r, r)
+					int kind = -1, r = 0, c = 0;
+					for (int cc = a.c0; kind < 0 && cc < a.C1; ++cc)
+					{
+						bool hp;
+						int lo;
+						const int nu = dag_column_units(cc, a.C1, a.R, hp, lo);
+						if (u < nu)
+						{
+							c = cc;
+							if (!hp) kind = 0, r = lo + u;
+							else if (u == 0) kind = 0, r = cc + 2;
+							else if (u <= 2) kind = u, r = cc + 2;
+							else kind = 0, r = cc + u;
+						}
+						u -= nu;
+					}
+					if (kind < 0) return;
+					bool ok;
+					if (kind == 0) ok = dag_task(a, r, c, c, c, true, qa, dag_tile(a, r, c) + qa, lane);
+					else if (kind == 1) ok = dag_task(a, r, r - 1, r - 1, r - 1, false, qa, dag_pb(a, r) + qa, lane);
+					else ok = dag_task(a, r, r, r, r - 1, false, qa, dag_pc(a, r) + qa, lane);
+					if (!ok) return;
+				}
+			}
+			// ---- the spine: four waves, the schedule of potrf_step_kernel's panel waves
+			__shared__ __attribute__((aligned(16))) double S[NB * DLS];  // A_kk -> L_kk (strictly lower tiles)
+			__shared__ __attribute__((aligned(16))) double TI[NB * DLS]; // T_k; before the chains of panel k: L(k, k - 1), k-major (D)
+			__shared__ double rinv[NB];
+			double* const D = TI;
+			const int fr = lane & 15, fk = lane >> 4;
+			auto Sx = [&](int ti, int tj) { return S + ti * 16 * DLS + tj * 16; };
+			auto Tx = [&](int ti, int tj) { return TI + ti * 16 * DLS + tj * 16; };
+			auto upd = [&](int ti, int tj, int sp) {
+				d4v acc = tile_load(Sx(ti, tj), lane);
+				acc = tile_mac<true, true, 16>(acc, Sx(ti, sp), Sx(tj, sp), lane);
+				tile_store(Sx(ti, tj), acc, lane);
+			};
+			auto pend_upd = [&](int ti, int tj) {
+				d4v acc = tile_load(Sx(ti, tj), lane);
+				acc = tile_mac_kk_neg64(acc, D + ti * 16, D + tj * 16, lane);
+				tile_store(Sx(ti, tj), acc, lane);
+			};
+			auto pend_upd2 = [&](int aa, int ca, int b, int c, bool first_t) {
+				d4v acc0 = first_t ? tile_load_t(Sx(aa, ca), lane) : tile_load(Sx(aa, ca), lane);
+				d4v acc1 = tile_load(Sx(b, c), lane);
+				tile_mac2_kk_neg64(acc0, acc1, D + (first_t ? ca : aa) * 16, D + b * 16, D + (first_t ? aa : c) * 16, lane);
+				if (first_t) tile_store_t(Sx(aa, ca), acc0, lane);
+				else tile_store(Sx(aa, ca), acc0, lane);
+				tile_store(Sx(b, c), acc1, lane);
+			};
+			auto v_acc = [&](int i, int b, int k, bool first) {
+				d4v acc = {0.0, 0.0, 0.0, 0.0};
+				if (!first) acc = tile_load(Tx(i, b), lane);
+				acc = tile_mac<false, false, 16>(acc, Sx(i, k), Tx(k, b), lane);
+				tile_store(Tx(i, b), acc, lane);
+			};
+			auto t_fin = [&](int i, int b) {
+				d4v acc = {0.0, 0.0, 0.0, 0.0};
+				acc = tile_mac<false, true, 16>(acc, Tx(i, i), Tx(i, b), lane);
+				tile_store(Tx(i, b), acc, lane);
+			};
+			// No barrier of the spine waits for memory: LDS only (s_waitcnt lgkmcnt(0); s_barrier).  What the workers wait for leaves as early as it
+			// exists — L(k, k - 1) straight from the product's registers, the last tile row of T_k from those of its last products — and is flagged
+			// by the wave that stored it after a wait of its own, placed where the stores are a stage old; what comes in for the next panel is
+			// requested as soon as wave 1 has seen its flags.
+			auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+			// rows 16 q4 .. 16 q4 + 15, columns [c_lo, c_lo + 16 nct) of T_k from TI to the diagonal block of T (zeros above the diagonal)
+			auto store_t_rows = [&](int k, int q4, int c_lo, int nct) {
+				double* __restrict__ Tkk = a.T + static_cast<long>(k) * NB * (a.ldt + 1);
+				const int rr = 16 * q4 + fr;
+				for (int q = 0; q < 4 * nct; ++q)
+				{
+					const int c = c_lo + fk + 4 * q;
+					stc(Tkk + rr + static_cast<long>(c) * a.ldt, c <= rr ? TI[rr * DLS + c] : 0.0);
+				}
+			};
+			// the block above an odd diagonal block of T: see potrf_step_kernel
+			auto zero_above = [&](int k) {
+				double* __restrict__ Tab = a.T + static_cast<long>(k) * NB * (a.ldt + 1) - NB;
+#pragma unroll
+				for (int q = 0; q < 64; ++q) stc(Tab + lane + static_cast<long>(q) * a.ldt, 0.0);
+			};
+			// T(3, b) = -T(3, 3) V(3, b): to TI for the next panel's first product and straight to memory
+			auto t_fin_out = [&](int k, int b) {
+				d4v acc = {0.0, 0.0, 0.0, 0.0};
+				acc = tile_mac<false, true, 16>(acc, Tx(3, 3), Tx(3, b), lane);
+				tile_store(Tx(3, b), acc, lane);
+				double* __restrict__ Tkk = a.T + static_cast<long>(k) * NB * (a.ldt + 1);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) stc(Tkk + 48 + fk + 4 * r + static_cast<long>(16 * b + fr) * a.ldt, acc[r]);
+			};
+			__builtin_amdgcn_s_setprio(3);
+			// A~(k, k): waves 1-3, a row per lane (512 contiguous bytes per load: anything less is a gather to the address unit, ~60 cycles an instruction),
+			// 21 or 22 columns per wave; the 8-way bank conflict on the way into S is the lesser evil.  Wave 0 loads none: its issue slots belong to the
+			// chains.  A~(k, k - 1): row tile w as operand fragments, every wave (gathers: 16 rows x 4 columns each).
+			double sreg[22], bx[16];
+			bool have = false;        // ... already requested for the coming panel
+			__shared__ int nxt_ready; // wave 1 watches the flags of the coming panel's pre-tiles for everybody
+			if (t == 0) nxt_ready = -1;
+			const int sc0 = 21 * (w - 1); // 22 columns per wave (waves 1 / 2 and 2 / 3 share one): the same count everywhere, for the s_waitcnt below
+			constexpr int scn = 22;
+			// A~(k, k - 1) is asked for a stage or two ahead (the panel's first product needs it at once); A~(k, k) at the top of the panel — it is not
+			// needed before that product and two barriers are through, and 44 registers less live through the chains
+			auto request_inputs = [&](int k) {
+				if (k > a.c0)
+				{
+					const double* __restrict__ Bt = a.A + static_cast<long>(k) * NB * (a.lda + 1) - static_cast<long>(NB) * a.lda + 16 * w + fr;
+#pragma unroll
+					for (int q = 0; q < 16; ++q) bx[q] = ldc(Bt + static_cast<long>(4 * q + fk) * a.lda);
+				}
+			};
+			auto request_diag = [&](int k) {
+				const double* __restrict__ Akk = a.A + static_cast<long>(k) * NB * (a.lda + 1);
+				if (w > 0)
+#pragma unroll
+					for (int q = 0; q < 22; ++q) sreg[q] = ldc(Akk + lane + static_cast<long>(sc0 + q) * a.lda);
+			};
+			// the eight flags of the two pre-tiles of row k, one per lane (the rest repeat them)
+			auto pre_flag_ptr = [&](int k) { return (lane & 4 ? dag_pc(a, k) : dag_pb(a, k)) + (lane & 3); };
+			for (int k = a.c0; k < a.C1; ++k)
+			{
+				const int j0 = k * NB;
+				const bool pend = k > a.c0;
+				auto stamp = [&](int i) {
+					if (a.stamps != nullptr && t == 0) a.stamps[16 * k + i] = wall_clock64();
+				};
+				stamp(0);
+				if (!have)
+				{
+					if (k >= a.c0 + 2 && !dag_wait(a, dag_pb(a, k), dag_pc(a, k), nullptr, lane)) break;
+					request_inputs(k);
+				}
+				have = false;
+				request_diag(k);
+				stamp(1);
+				int first_bad = 0;
+				if (pend)
+				{
+					// L(k, k - 1) = A~(k, k - 1) T_{k-1}^T: row tile w, column tile j over k <= 16 j + 15
+					d4v lo[4];
+					[&]<int... Js>(std::integer_sequence<int, Js...>)
+					{
+						(
+							[&] {
+								constexpr int j = Js;
+								d4v o = {0.0, 0.0, 0.0, 0.0};
+								double y[4 * (j + 1)];
+#pragma unroll
+								for (int q = 0; q < 4 * (j + 1); ++q) y[q] = TI[(16 * j + fr) * DLS + 4 * q + fk];
+#pragma unroll
+								for (int q = 0; q < 4 * (j + 1); ++q) o = __builtin_amdgcn_mfma_f64_16x16x4f64(bx[q], y[q], o, 0, 0, 0);
+								lo[j] = o;
+							}(),
+							...);
+					}
+					(std::make_integer_sequence<int, 4>{});
+					// T_{k-1}: the wave's stores are a product and a stage old; only the 22 loads of A~(k, k) are younger
+					if (w > 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+					else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					if (lane == 0) stf(dag_t(a, k - 1) + w, a.epoch);
+					stamp(2);
+					lds_barrier(); // everybody has read T_{k-1}: its place takes L(k, k - 1), k-major
+#pragma unroll
+					for (int j = 0; j < 4; ++j) tile_store_t(D + j * 16 * DLS + w * 16, lo[j], lane);
+				}
+				if (w > 0)
+#pragma unroll
+					for (int q = 0; q < 22; ++q) S[lane * DLS + sc0 + q] = sreg[q];
+				lds_barrier();
+				if (pend)
+				{
+					// L(k, k - 1) leaves from D, a column (64 contiguous rows) per instruction, waves 1-3; flagged by wave 1 once all three have waited
+					if (w > 0)
+					{
+						double* __restrict__ Lg = a.A + j0 + lane + static_cast<long>(j0 - NB) * a.lda;
+						for (int c = sc0 + (w > 1); c < sc0 + scn; ++c) stc(Lg + static_cast<long>(c) * a.lda, D[c * DLS + lane]);
+					}
+					pend_upd(w, 0);
+					if (w > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					lds_barrier();
+					if (w == 1 && lane < 4) stf(dag_tile(a, k, k - 1) + lane, a.epoch);
+				}
+				stamp(3);
+				if (w == 0) diag_chain<0>(S, rinv, lane, first_bad);
+				else if (pend)
+				{
+					if (w == 1) pend_upd2(1, 1, 2, 1, false);
+					else if (w == 2) pend_upd2(2, 2, 3, 2, false);
+					else pend_upd2(3, 1, 3, 3, true);
+				}
+				lds_barrier();
+				stamp(4);
+				if (w == 0) upd(1, 1, 0);
+				else if (w == 1) upd(2, 1, 0);
+				else if (w == 2) upd(3, 1, 0);
+				else upd(2, 2, 0);
+				lds_barrier();
+				stamp(5);
+				if (w == 0) diag_chain<1>(S, rinv, lane, first_bad);
+				else if (w == 1) diag_inv16(S, rinv, TI, 0, lane);
+				else if (w == 2) upd(3, 2, 0);
+				else
+				{
+					upd(3, 3, 0);
+					if (k & 1) zero_above(k);
+				}
+				lds_barrier();
+				stamp(6);
+				if (w == 0) upd(2, 2, 1);
+				else if (w == 1) upd(3, 2, 1);
+				else if (w == 2) upd(3, 3, 1);
+				else v_acc(1, 0, 0, true);
+				lds_barrier();
+				stamp(7);
+				// the coming panel's inputs: wave 1 looks at its pre-tiles' flags once per stage from here on (a load whose answer the next stage reads)
+				// and tells the others through LDS; the tiles are requested a stage after the flags are seen — wave 0 not before its last chain is done
+				const bool next_in = k + 1 < a.C1;
+				const bool next_flags = k + 1 >= a.c0 + 2;
+				int pf = a.epoch - 1;
+				bool asked = false;
+				auto poll = [&] { // wave 1
+					if (!next_in || !next_flags || nxt_ready == k + 1) return;
+					if (asked && __all(pf - a.epoch >= 0))
+					{
+						if (lane == 0) nxt_ready = k + 1;
+						return;
+					}
+					pf = ldf(pre_flag_ptr(k + 1)), asked = true;
+				};
+				auto look = [&] {
+					if (next_in && !have && (!next_flags || nxt_ready == k + 1)) request_inputs(k + 1), have = true;
+				};
+				if (w == 1) poll();
+				if (w == 0) diag_chain<2>(S, rinv, lane, first_bad);
+				else if (w == 1) diag_inv16(S, rinv, TI, 1, lane);
+				else if (w == 2) v_acc(2, 0, 0, true);
+				else v_acc(3, 0, 0, true);
+				lds_barrier();
+				stamp(8);
+				if (w == 1) poll();
+				if (w == 0) upd(3, 3, 2);
+				else if (w == 1) t_fin(1, 0);
+				else if (w == 2) v_acc(2, 1, 1, true);
+				else v_acc(3, 1, 1, true);
+				lds_barrier();
+				stamp(9);
+				if (w == 1) poll();
+				if (w > 1) look();
+				if (w == 0) diag_chain<3>(S, rinv, lane, first_bad);
+				else if (w == 1) diag_inv16(S, rinv, TI, 2, lane);
+				else if (w == 2) v_acc(2, 0, 1, false);
+				else
+				{
+					v_acc(3, 0, 1, false);
+					store_t_rows(k, 0, 0, 4), store_t_rows(k, 1, 0, 4); // complete since the barrier above
+				}
+				lds_barrier();
+				stamp(10);
+				if (w == 1) poll();
+				look();
+				if (w == 0) diag_inv16(S, rinv, TI, 3, lane);
+				else if (w == 1) t_fin(2, 0), v_acc(3, 0, 2, false); // LDS operations of one wave complete in order
+				else if (w == 2) t_fin(2, 1), v_acc(3, 1, 2, false);
+				else v_acc(3, 2, 2, true);
+				lds_barrier();
+				stamp(11);
+				look();
+				if (w < 3) t_fin_out(k, w);
+				else store_t_rows(k, 2, 0, 4), store_t_rows(k, 3, 48, 1);
+				if (first_bad != 0 && t == 0) atomicCAS(a.info, 0, j0 + first_bad);
+				lds_barrier();
+				stamp(12);
+				if (k + 1 == a.C1)
+				{
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					if (lane == 0) stf(dag_t(a, k) + w, a.epoch);
+				}
+			}
+			if (t == 0 && ldf(dag_err(a)) - a.epoch >= 0) atomicExch(a.info, -1);
+		}
+
 		// upper(i<j) = lower(j,i) for a full symmetric result
 		__global__ void __launch_bounds__(256) mirror_lower_kernel(double* __restrict__ W, long ldw, int n)
 		{
@@ -834,8 +1314,40 @@ namespace gple
 	// uvec != nullptr: A carries one more block row (rows n .. n + NB - 1, row n = the scaled labels y, the rest zero); it is factored
 	// along as part of every panel, which leaves u = L^-1 y in its first row — collected into uvec — at no extra launch
 	// on_final(j): called right after the launch that makes the columns [0, j) of the factor (and their T_jj) final, for every j in `marks`
+	// flags of the one-launch-per-panel-range scheme (potrf_dag_kernel): the context's buffer, sized for the largest matrix seen so far, and
+	// the epoch of this factorisation
+	struct DagState
+	{
+		int* flags;
+		int epoch;
+	};
+	namespace
+	{
+		__global__ void spin_stamp_kernel(long long* out) { if (threadIdx.x == 0) *out = wall_clock64(); }
+	} // namespace
+	static bool chol_dag_scheme()
+	{
+		static const bool v = [] {
+			const char* e = getenv("GPLE_CHOL_SCHEME"); // "step": one launch per panel (rounds 2-3); "dag" (default): one launch per outer block
+			return e == nullptr || std::string(e) != "step";
+		}();
+		return v;
+	}
+	static int chol_dag_max_blocks()
+	{
+		static const int v = [] {
+			if (const char* e = getenv("GPLE_CHOL_DAG_BLOCKS"))
+				if (atoi(e) >= 2) return atoi(e);
+			int dev = 0, cus = 0;
+			if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2) cus = 64;
+			return cus; // never more workgroups than CUs: every one of them must be resident for the first unfinished task to make progress
+		}();
+		return v;
+	}
+	static size_t chol_dag_flag_ints(int n) { return 4 * (static_cast<size_t>(n / NB + 4) * (n / NB) + 2); } // ticket counter, tile flags, three per column, error word
+
 	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end, double* uvec,
-		const std::vector<int>* marks = nullptr, const std::function<hipError_t(int)>* on_final = nullptr)
+		const std::vector<int>* marks = nullptr, const std::function<hipError_t(int)>* on_final = nullptr, const DagState* dag = nullptr)
 	{
 		const std::vector<int>& bounds = chol_block_bounds(n);
 		auto at = [&](int r, int c) { return A + r + static_cast<long>(c) * lda; };
@@ -853,6 +1365,77 @@ namespace gple
 			const char* e = getenv("GPLE_CHOL_FUSED");
 			return e == nullptr || atoi(e) != 0;
 		}();
+		if (dag != nullptr)
+		{
+			// outer block by outer block — the marks are block boundaries too, so that a launch never continues sums another launch began —:
+			// its panels in one launch, then the matrix right of it in one update
+			const int FS = n / NB, R = FS + (uvec ? 1 : 0);
+			std::vector<int> cuts(bounds);
+			if (marks) cuts.insert(cuts.end(), marks->begin(), marks->end());
+			if (marks)
+				cuts.erase(std::remove_if(cuts.begin(), cuts.end(),
+							   [&](int b) {
+								   if (b == 0 || b == n) return false;
+								   for (int m : *marks)
+									   if (b != m && std::abs(b - m) < 256) return true; // no sliver between a block bound and a mark: the mark stays
+								   return false;
+							   }),
+					cuts.end());
+			std::sort(cuts.begin(), cuts.end());
+			cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+			for (size_t bi = 0; bi + 1 < cuts.size(); ++bi)
+			{
+				const int J0 = cuts[bi], Jend = cuts[bi + 1];
+				if (J0 < j_begin || Jend > j_end) continue;
+				DagArgs g{};
+				g.A = A, g.lda = lda, g.T = T, g.ldt = ldt, g.info = info, g.uvec = uvec, g.flags = dag->flags + 4, g.FS = FS, g.R = R;
+				g.c0 = J0 / NB, g.C1 = Jend / NB, g.epoch = dag->epoch;
+				g.nunits = dag_count_units(g.c0, g.C1, R);
+				g.seq = static_cast<int>(bi);
+				const int helpers = std::min(chol_dag_max_blocks() - 1, g.nunits);
+				constexpr int LAST_STAMP = 12;
+				static const bool want_stamps = getenv("GPLE_CHOL_DAG_STAMPS") != nullptr;
+				static long long* stamp_buf = nullptr;
+				if (want_stamps && stamp_buf == nullptr && hipMalloc(reinterpret_cast<void**>(&stamp_buf), 16 * 1024 * sizeof(long long)) != hipSuccess) stamp_buf = nullptr;
+				g.stamps = want_stamps && FS <= 1000 ? stamp_buf : nullptr;
+				if (g.stamps)
+				{
+					const hipError_t e = hipMemsetAsync(stamp_buf, 0, 16 * 1024 * sizeof(long long), s);
+					if (e != hipSuccess) return e;
+					hipLaunchKernelGGL(spin_stamp_kernel, dim3(1), dim3(64), 0, s, stamp_buf + 16 * 1023);
+				}
+				hipLaunchKernelGGL(potrf_dag_kernel, dim3(1 + helpers), dim3(256), 0, s, g);
+				if (g.stamps)
+				{
+					hipLaunchKernelGGL(spin_stamp_kernel, dim3(1), dim3(64), 0, s, stamp_buf + 16 * 1023 + 1);
+					std::vector<long long> h(16 * 1024);
+					if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), stamp_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess)
+					{
+						fprintf(stderr, "dag launch: panels [%d, %d), %d units, %d workgroups: %.2f us between the stamps around it\n", g.c0, g.C1, g.nunits, 1 + helpers,
+							(h[16 * 1023 + 1] - h[16 * 1023]) * 0.01);
+						for (int k = g.c0; k < g.C1; ++k)
+						{
+							const long long* q = h.data() + 16 * k;
+							fprintf(stderr, "  panel %3d: start %8.2f |", k, (q[0] - h[16 * 1023]) * 0.01);
+							for (int i = 1; i <= LAST_STAMP; ++i) fprintf(stderr, " %5.2f", (q[i] - q[i - 1]) * 0.01);
+							fprintf(stderr, " | step %6.2f\n", (q[LAST_STAMP] - q[0]) * 0.01);
+						}
+					}
+				}
+				if (marks && std::find(marks->begin(), marks->end(), Jend) != marks->end())
+				{
+					const hipError_t e = (*on_final)(Jend);
+					if (e != hipSuccess) return e;
+				}
+				if (n - Jend > 0)
+				{
+					const int extra = uvec ? NB : 0;
+					const hipError_t e = syrk_update(Jend, n + extra - Jend, n - Jend, J0, Jend - J0);
+					if (e != hipSuccess) return e;
+				}
+			}
+			return hipGetLastError();
+		}
 		bool pend = false; // the rank-64 update by the previous panel has not been applied yet (fused scheme: it rides in the next launch)
 		for (int j0 = j_begin; j0 < j_end; j0 += NB)
 		{
@@ -927,10 +1510,36 @@ namespace gple
 		return hipGetLastError();
 	}
 
-	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec)
+	// the context's flag buffer for the one-launch scheme, grown to the matrix at hand, and a fresh epoch
+	static hipError_t dag_state(Ctx* ctx, hipStream_t s, int n, DagState& st)
+	{
+		const size_t need = chol_dag_flag_ints(n);
+		if (ctx->dag_flags_ints < need)
+		{
+			if (ctx->dag_flags) (void)hipFree(ctx->dag_flags);
+			ctx->dag_flags = nullptr, ctx->dag_flags_ints = 0;
+			hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->dag_flags), need * sizeof(int));
+			if (e != hipSuccess) return e;
+			if ((e = hipMemsetAsync(ctx->dag_flags, 0, need * sizeof(int), s)) != hipSuccess) return e;
+			ctx->dag_flags_ints = need;
+			ctx->dag_epoch = 0;
+		}
+		st.flags = ctx->dag_flags;
+		st.epoch = ++ctx->dag_epoch;
+		return hipSuccess;
+	}
+
+	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec, Ctx* ctx)
 	{
 		if (n % NB) return hipErrorInvalidValue;
-		const hipError_t e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n, uvec);
+		DagState st{};
+		const bool use_dag = ctx != nullptr && chol_dag_scheme();
+		if (use_dag)
+		{
+			const hipError_t e = dag_state(ctx, s, n, st);
+			if (e != hipSuccess) return e;
+		}
+		const hipError_t e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n, uvec, nullptr, nullptr, use_dag ? &st : nullptr);
 		if (e != hipSuccess) return e;
 		return hipGetLastError();
 	}
@@ -1168,7 +1777,7 @@ namespace gple
 		const std::vector<int>& forks = chol_fork_points(n);
 		if (n < chol_overlap_min_n() || nblocks < 4 || forks.empty())
 		{
-			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info, uvec);
+			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info, uvec, ctx);
 			if (e != hipSuccess) return e;
 			return trtri_lower_from_diag(s, A, lda, T, ldt, n, work);
 		}
@@ -1225,7 +1834,10 @@ namespace gple
 			if (nfork == forks.size()) er = w_product(side, j, n);
 			return er;
 		};
-		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n, uvec, &forks, &on_final)) != hipSuccess) return e;
+		DagState dst{};
+		const bool use_dag = chol_dag_scheme();
+		if (use_dag && (e = dag_state(ctx, s, n, dst)) != hipSuccess) return e;
+		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n, uvec, &forks, &on_final, use_dag ? &dst : nullptr)) != hipSuccess) return e;
 		if ((e = hipEventRecord(ctx->side_join, side)) != hipSuccess) return e;
 		// the last row block: its tree does not need the side's results, the last product does
 		if ((e = tree(s, done, n, w_main)) != hipSuccess) return e;

@@ -80,6 +80,10 @@ namespace gple
 		int side_attempts = 0;       // candidate streams tried until one ran beside the main stream (pick_side_stream)
 		bool side_overlaps = false;  // the chosen one did
 		hipEvent_t side_join = nullptr;
+		// flags of the factorisation's one-launch scheme (gple_chol.hip, potrf_dag_kernel): never cleared, every factorisation takes a new epoch
+		int* dag_flags = nullptr;
+		size_t dag_flags_ints = 0;
+		int dag_epoch = 0;
 		std::vector<hipEvent_t> side_forks;
 		// pinned host block for scalar results
 		double* host_scalars = nullptr;
@@ -150,7 +154,7 @@ namespace gple
 	// diagonal blocks of the factor are never stored: on return T (n x n, ldt) holds inv(L_jj) in every diagonal block (full
 	// 64 x 64 blocks, zeros above the diagonal), i.e. the diagonal blocks of T = L^-1 (potrf_diag_kernel).  info (device int): 0 or 1 + index of the
 	// first non-positive pivot.
-	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec = nullptr);
+	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec = nullptr, Ctx* ctx = nullptr);
 	hipError_t debug_potrf_diag(hipStream_t s, const double* A, double* T, int* info, long long* stamps);
 	void chol_layout(int n, std::vector<int>& bounds, std::vector<int>& forks, size_t& work_doubles);
 	hipError_t debug_potrf_step(hipStream_t s, double* A, long lda, double* T, long ldt, int* info, long long* stamps, int pend, int below);
