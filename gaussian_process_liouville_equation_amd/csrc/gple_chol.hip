@@ -780,6 +780,9 @@ namespace gple
 		// spine needs next first), so with every workgroup resident — the grid never exceeds one per CU — the first unfinished task can always run.
 		// Every wait is bounded: after DAG_POLL_LIMIT polls a wave raises the error flag, everybody leaves, and *info becomes -1.
 		constexpr int DAG_POLL_LIMIT = 1 << 21;
+#ifndef DAG_POLL_SLEEP
+#define DAG_POLL_SLEEP 8
+#endif
 		struct DagArgs
 		{
 			double* A;
@@ -822,7 +825,7 @@ namespace gple
 					return true;
 				}
 				if ((it & 31) == 31 && ldf(err) - a.epoch >= 0) return false;
-				__builtin_amdgcn_s_sleep(2);
+				__builtin_amdgcn_s_sleep(DAG_POLL_SLEEP);
 			}
 			if (lane == 0) stf(dag_err(a), a.epoch), atomicExch(a.info, -1);
 			return false;
@@ -1392,7 +1395,15 @@ namespace gple
 				g.c0 = J0 / NB, g.C1 = Jend / NB, g.epoch = dag->epoch;
 				g.nunits = dag_count_units(g.c0, g.C1, R);
 				g.seq = static_cast<int>(bi);
-				const int helpers = std::min(chol_dag_max_blocks() - 1, g.nunits);
+				// once the side stream is at work (from the first mark on) the launch leaves part of the chip to its GEMMs: a workgroup of this kernel
+				// holds 70 KB of LDS on its CU whether it works or waits, which halves the GEMM workgroups that fit beside it
+				static const int late_blocks = [] {
+					const char* e = getenv("GPLE_CHOL_DAG_LATE_BLOCKS");
+					return e ? atoi(e) : 64; // 0: no limit.  n = 4096: 1.85 / 1.85 / 1.79 / 1.81 ms with 256 / 128 / 64 / 32 workgroups
+				}();
+				const bool side_busy = marks != nullptr && !marks->empty() && J0 >= marks->front();
+				const int max_blocks = side_busy && late_blocks >= 2 ? std::min(late_blocks, chol_dag_max_blocks()) : chol_dag_max_blocks();
+				const int helpers = std::min(max_blocks - 1, g.nunits);
 				constexpr int LAST_STAMP = 12;
 				static const bool want_stamps = getenv("GPLE_CHOL_DAG_STAMPS") != nullptr;
 				static long long* stamp_buf = nullptr;
@@ -1648,28 +1659,61 @@ namespace gple
 	// Workspace of chol_inverse_factor, from the fork list actually in use (GPLE_CHOL_FORKS may put the forks anywhere): W = L(g, 0..g0) T(0..g0)
 	// of the widest row block product, the merge tree of the widest side job, the merge tree of the last row block (a tree over b columns needs
 	// b^2 / 4 doubles: count * s1 * s2 per level); the unsplit path uses one tree of n^2 / 4 at the front
+	// The row blocks of the inverse = where the side stream is handed finished columns: the fork points (GPLE_CHOL_MARKS=cuts: every outer block
+	// boundary of the one-launch scheme as well — a launch ends there anyway —, measured slower: the side stream's GEMMs run at a fraction of
+	// their speed beside a panel launch, and more, smaller ones do worse).  Empty: no overlap (small matrices).
+	static const std::vector<int>& chol_marks(int n)
+	{
+		static std::mutex mu;
+		static std::map<int, std::vector<int>> cache;
+		std::lock_guard<std::mutex> lk(mu);
+		auto it = cache.find(n);
+		if (it != cache.end()) return it->second;
+		std::vector<int> m;
+		const std::vector<int>& forks = chol_fork_points(n);
+		if (n >= chol_overlap_min_n() && n / NB >= 4 && !forks.empty())
+		{
+			m = forks;
+			static const bool all_cuts = [] {
+				const char* e = getenv("GPLE_CHOL_MARKS"); // "cuts": every outer block boundary as well (A/B: 1.86 vs 1.83 ms at n = 4096, 9.15 vs 8.91 at 8192)
+				return e != nullptr && std::string(e) == "cuts";
+			}();
+			if (chol_dag_scheme() && all_cuts)
+			{
+				for (int b : chol_block_bounds(n))
+				{
+					bool keep = b > 0 && b < n;
+					for (int f : forks) keep = keep && std::abs(b - f) >= 256;
+					if (keep) m.push_back(b);
+				}
+				std::sort(m.begin(), m.end());
+			}
+		}
+		return cache.emplace(n, std::move(m)).first->second;
+	}
 	struct InvWork
 	{
 		size_t prod, side, main;
 	};
+	// prod: W(rows below the first mark, columns left of the last one), accumulated block row by block row (chol_inverse_factor); side / main: the
+	// merge trees of the widest side job / of the last row block (b^2 / 4 doubles for b columns); without marks one tree over all n columns
 	static InvWork chol_inverse_work_split(int n)
 	{
 		const auto sq4 = [](size_t b) { return b * b / 4; };
 		InvWork w{0, 0, 0};
-		const std::vector<int>& forks = chol_fork_points(n);
-		if (n < chol_overlap_min_n() || n / NB < 4 || forks.empty())
+		const std::vector<int>& marks = chol_marks(n);
+		if (marks.empty())
 		{
 			w.prod = sq4(static_cast<size_t>(n));
 			return w;
 		}
 		size_t done = 0;
-		for (int j : forks)
+		for (int j : marks)
 		{
 			w.side = std::max(w.side, sq4(static_cast<size_t>(j) - done));
-			w.prod = std::max(w.prod, (static_cast<size_t>(j) - done) * done);
 			done = static_cast<size_t>(j);
 		}
-		w.prod = std::max(w.prod, (static_cast<size_t>(n) - done) * done);
+		w.prod = (static_cast<size_t>(n) - marks.front()) * static_cast<size_t>(marks.back());
 		w.main = sq4(static_cast<size_t>(n) - done);
 		return w;
 	}
@@ -1773,9 +1817,8 @@ namespace gple
 	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work, double* uvec)
 	{
 		if (n % NB) return hipErrorInvalidValue;
-		const int nblocks = n / NB;
-		const std::vector<int>& forks = chol_fork_points(n);
-		if (n < chol_overlap_min_n() || nblocks < 4 || forks.empty())
+		const std::vector<int>& marks = chol_marks(n);
+		if (marks.empty())
 		{
 			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info, uvec, ctx);
 			if (e != hipSuccess) return e;
@@ -1787,7 +1830,7 @@ namespace gple
 			if ((e = pick_side_stream(ctx, s)) != hipSuccess) return e;
 			if ((e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming)) != hipSuccess) return e;
 		}
-		while (ctx->side_forks.size() < forks.size())
+		while (ctx->side_forks.size() < marks.size())
 		{
 			hipEvent_t ev;
 			if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
@@ -1795,23 +1838,37 @@ namespace gple
 		}
 		hipStream_t side = ctx->side_stream;
 		const InvWork iw = chol_inverse_work_split(n);
-		double* w_prod = work;                     // W of the row block in flight (side jobs are serial; the last one runs after the join)
+		// T = L^-1 by block rows, right-looking in W: T(g, 0..g0) = -T_gg W(g, 0..g0) with W(g, .) = sum over the row blocks m above g of
+		// L(g, m) T(m, .).  As soon as row block m of T is complete its term goes into the W of EVERY row below — so what is left behind the
+		// last panel is the last row block's own tree and one product, not the whole history of its W (round 3: W of the last rows was formed in
+		// one piece after the last fork, 0.2 ms of side stream work the main stream waited for at n = 4096).
+		const int f1 = marks.front();
+		const long ldw = n - f1;
+		double* w_all = work;                      // W(r, c) at (r - f1) + c * ldw, rows below the first mark
 		double* w_side = work + iw.prod;           // merge tree of a side job
 		double* w_main = work + iw.prod + iw.side; // merge tree of the last row block (main stream, beside the side's last job)
-		// row block [g0, g1) of T: its diagonal block by the merge tree, W = L(g, 0..g0) T(0..g0, 0..g0), T(g, 0..g0) = -T_gg W
 		auto tree = [&](hipStream_t st, int g0, int g1, double* w_tree) -> hipError_t {
 			return trtri_lower_from_diag(st, A + g0 + static_cast<long>(g0) * lda, lda, T + g0 + static_cast<long>(g0) * ldt, ldt, g1 - g0, w_tree, g0);
 		};
-		auto w_product = [&](hipStream_t st, int g0, int g1) -> hipError_t {
+		// W(rows j .. n, .) (+)= L(rows, g0 .. g1) T(g0 .. g1, .): columns left of the block dense (T(g, 0..g0), just completed), the block's own
+		// columns against its triangular diagonal block (their first term)
+		auto w_accumulate = [&](hipStream_t st, int g0, int g1) -> hipError_t {
 			GemmDesc g{};
-			g.A = A + g0, g.lda = lda, g.B = T, g.ldb = ldt, g.C = w_prod, g.ldc = g1 - g0;
-			g.M = g1 - g0, g.N = g0, g.K = g0, g.batch = 1, g.alpha = 1.0, g.beta = 0.0;
-			g.krange = K_GE_N, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
-			return launch_gemm(st, g, tri_tile(g1 - g0, g0, 1, g0));
+			g.A = A + g1 + static_cast<long>(g0) * lda, g.lda = lda, g.ldb = ldt, g.ldc = ldw;
+			g.M = n - g1, g.K = g1 - g0, g.batch = 1, g.alpha = 1.0;
+			g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
+			if (g0 > 0)
+			{
+				g.B = T + g0, g.C = w_all + (g1 - f1), g.N = g0, g.beta = 1.0, g.krange = K_FULL;
+				const hipError_t er = launch_gemm(st, g, gemm_pick_tile(g.M, g.N, 1, false));
+				if (er != hipSuccess) return er;
+			}
+			g.B = T + g0 + static_cast<long>(g0) * ldt, g.C = w_all + (g1 - f1) + static_cast<long>(g0) * ldw, g.N = g1 - g0, g.beta = 0.0, g.krange = K_GE_N;
+			return launch_gemm(st, g, tri_tile(g.M, g.N, 1, g0));
 		};
 		auto t_product = [&](hipStream_t st, int g0, int g1) -> hipError_t {
 			GemmDesc g{};
-			g.A = T + g0 + static_cast<long>(g0) * ldt, g.lda = ldt, g.B = w_prod, g.ldb = g1 - g0, g.C = T + g0, g.ldc = ldt;
+			g.A = T + g0 + static_cast<long>(g0) * ldt, g.lda = ldt, g.B = w_all + (g0 - f1), g.ldb = ldw, g.C = T + g0, g.ldc = ldt;
 			g.M = g1 - g0, g.N = g0, g.K = g1 - g0, g.batch = 1, g.alpha = -1.0, g.beta = 0.0;
 			g.krange = K_LE_M, g.lower_only = 0, g.a_kmajor = false, g.b_kmajor = true, g.c_trans = false;
 			return launch_gemm(st, g, tri_tile(g1 - g0, g0, 1, g0));
@@ -1824,20 +1881,15 @@ namespace gple
 			if ((er = hipEventRecord(ev, s)) != hipSuccess) return er;
 			if ((er = hipStreamWaitEvent(side, ev, 0)) != hipSuccess) return er;
 			if ((er = tree(side, done, j, w_side)) != hipSuccess) return er;
-			if (done > 0)
-			{
-				if ((er = w_product(side, done, j)) != hipSuccess) return er;
-				if ((er = t_product(side, done, j)) != hipSuccess) return er;
-			}
+			if (done > 0 && (er = t_product(side, done, j)) != hipSuccess) return er;
+			if ((er = w_accumulate(side, done, j)) != hipSuccess) return er;
 			done = j;
-			// the rows below the last fork are final in these columns too: their W is formed here, beside the remaining panels
-			if (nfork == forks.size()) er = w_product(side, j, n);
-			return er;
+			return hipSuccess;
 		};
 		DagState dst{};
 		const bool use_dag = chol_dag_scheme();
 		if (use_dag && (e = dag_state(ctx, s, n, dst)) != hipSuccess) return e;
-		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n, uvec, &forks, &on_final, use_dag ? &dst : nullptr)) != hipSuccess) return e;
+		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n, uvec, &marks, &on_final, use_dag ? &dst : nullptr)) != hipSuccess) return e;
 		if ((e = hipEventRecord(ctx->side_join, side)) != hipSuccess) return e;
 		// the last row block: its tree does not need the side's results, the last product does
 		if ((e = tree(s, done, n, w_main)) != hipSuccess) return e;
@@ -1850,7 +1902,7 @@ namespace gple
 	void chol_layout(int n, std::vector<int>& bounds, std::vector<int>& forks, size_t& work_doubles)
 	{
 		bounds = chol_block_bounds(n);
-		forks = n >= chol_overlap_min_n() && n / NB >= 4 ? chol_fork_points(n) : std::vector<int>{};
+		forks = chol_marks(n);
 		work_doubles = chol_inverse_work_doubles(n);
 	}
 

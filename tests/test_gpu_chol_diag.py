@@ -168,3 +168,57 @@ def test_side_stream_lands_on_its_own_hardware_queue(pre):
         f.release()
     finally:
         api.close()
+
+
+def _fit_in_own_process(env, sizes):
+    """v, error and the fit's identities from a fit in a process of its own (the factorisation's knobs are read once per process)"""
+    import os, subprocess, sys, tempfile
+    from tests.conftest import ROOT
+    out = tempfile.mktemp(suffix=".npz")
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import gaussian_process_liouville_equation_amd as pkg
+from gaussian_process_liouville_equation_amd import _capi as c
+from tests import parity
+api = pkg.open_api(0)
+res = {}
+for N in %r:
+    X, y, _ = parity.synthetic_real(N, 8, 4242 + N)
+    fit = api.real_fit([1.0, 0.7086, 0.7056, 1e-2], X, y, 3)
+    assert fit.scalars["info"] == 0
+    K, W, v, ys = fit.get(c.R_KERNEL), fit.get(c.R_INVERSE), fit.get(c.R_INVLBL), fit.get(c.R_LABEL)
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    assert n1(K @ W - np.eye(N)) <= 50 * N * parity.EPS * n1(K) * n1(W)
+    assert np.abs(K @ v - ys).max() <= 50 * N * parity.EPS * (n1(K) * np.abs(v).max() + np.abs(ys).max())
+    res["v%%d" %% N], res["e%%d" %% N] = v, fit.scalars["error"]
+    fit.release()
+np.savez(%r, **res)
+print("ok")
+''' % (ROOT, list(sizes), out)
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
+    data = dict(np.load(out))
+    os.remove(out)
+    return data
+
+
+def test_one_launch_per_outer_block_against_one_launch_per_panel():
+    """gple_chol.hip: the factorisation's default scheme (potrf_dag_kernel: the panels of an outer block in one launch, tile tasks from a work queue,
+    hand-over by flags) and the scheme of rounds 2-3 (GPLE_CHOL_SCHEME=step: a launch per panel) are two summation orders of the same
+    factorisation: each satisfies the fit's identities, and v = K^-1 y agrees to what the conditioning allows.  Sizes: one outer block without /
+    with a fork of the inverse, several outer blocks (4096)."""
+    sizes = (512, 1024, 2304, 4096)
+    a = _fit_in_own_process({"GPLE_CHOL_SCHEME": "dag"}, sizes)
+    b = _fit_in_own_process({"GPLE_CHOL_SCHEME": "step"}, sizes)
+    for N in sizes:
+        va, vb = a["v%d" % N], b["v%d" % N]
+        assert np.abs(va - vb).max() <= 1e-7 * np.abs(vb).max(), N
+        assert abs(a["e%d" % N] - b["e%d" % N]) <= 1e-7 * b["e%d" % N], N
+
+
+def test_work_queue_makes_progress_with_one_worker_workgroup():
+    """the tile tasks of potrf_dag_kernel are handed out in dependency order from one counter, so the launch must complete with ANY number of its
+    workgroups running (the situation of a chip shared with other work): here one worker workgroup beside the spine (GPLE_CHOL_DAG_BLOCKS=2) —
+    4096 / 64 = 64 panels, four launches, about 60 ms instead of 2"""
+    _fit_in_own_process({"GPLE_CHOL_DAG_BLOCKS": "2"}, (1024, 4096))
