@@ -796,6 +796,8 @@ namespace gple
 			int c0, C1; // the panels of this launch, an outer block of the factorisation: sums start at c0, rows below C1 are spine rows
 			int epoch, nunits, seq; // units of work (tiles: four quarter tasks each); number of this launch within the factorisation
 			long long* stamps; // probe (GPLE_CHOL_DAG_STAMPS): 8 wall-clock stamps per panel of the spine, or nullptr
+			double* Tt;        // the launch also forms T = L^-1 below the diagonal blocks (matrices of one outer block): scratch of FS x FS tiles of
+			                   // 64 x 64, tile (r, c) = T(r, c)^T (what the tiles below it multiply with), or nullptr
 		};
 		__device__ __forceinline__ double ldc(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 		__device__ __forceinline__ void stc(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -806,11 +808,12 @@ namespace gple
 		__device__ __forceinline__ int* dag_pb(const DagArgs& a, int k) { return a.flags + 4 * (static_cast<long>(a.R + 1) * a.FS + k); }
 		__device__ __forceinline__ int* dag_pc(const DagArgs& a, int k) { return a.flags + 4 * (static_cast<long>(a.R + 2) * a.FS + k); }
 		__device__ __forceinline__ int* dag_err(const DagArgs& a) { return a.flags + 4 * static_cast<long>(a.R + 3) * a.FS; }
+		__device__ __forceinline__ int* dag_tt(const DagArgs& a, int r, int c) { return a.flags + 4 * (static_cast<long>(a.R + 3) * a.FS + 1 + static_cast<long>(r) * a.FS + c); }
 		// the ticket counter of the work queue: in front of the flags, at the same place whatever the matrix size — its high word outgrows every epoch
 		// and must never be read as a flag
 		__device__ __forceinline__ unsigned long long* dag_tickets(const DagArgs& a) { return reinterpret_cast<unsigned long long*>(a.flags - 4); }
 		// the whole wave waits until the four quarter flags at f4 and (if given) the four at g4 and the single flag at f1 carry this epoch
-		__device__ __forceinline__ bool dag_wait(const DagArgs& a, const int* f4, const int* g4, const int* f1, int lane)
+		__device__ __forceinline__ bool dag_wait(const DagArgs& a, const int* f4, const int* g4, const int* f1, int lane, bool patient = false)
 		{
 			const int* p = f4 + (lane & 3);
 			if (g4 != nullptr && (lane & 4)) p = g4 + (lane & 3);
@@ -825,7 +828,10 @@ namespace gple
 					return true;
 				}
 				if ((it & 31) == 31 && ldf(err) - a.epoch >= 0) return false;
-				__builtin_amdgcn_s_sleep(DAG_POLL_SLEEP);
+				// a task nobody will wait for soon looks less often: the polls of a thousand waiting waves go through the same memory system as
+				// the tiles the spine waits for
+				if (patient) __builtin_amdgcn_s_sleep(48);
+				else __builtin_amdgcn_s_sleep(DAG_POLL_SLEEP);
 			}
 			if (lane == 0) stf(dag_err(a), a.epoch), atomicExch(a.info, -1);
 			return false;
@@ -834,7 +840,7 @@ namespace gple
 		// (fin) the result is multiplied by T_cs^T; stored in place; *done = epoch.  Accumulator element acc[b][q] of lane (fr, fk) is entry
 		// (row 16 qa + fr, column 16 b + fk + 4 q) of the tile — also the layout of the MFMA operand "row fr, k = 4 (4 b + q) + fk", so the
 		// product with T_cs^T needs no transposition.
-		__device__ __forceinline__ bool dag_task(const DagArgs& a, int r, int xr, int cs, int iend, bool fin, int qa, int* done, int lane)
+		__device__ __forceinline__ bool dag_task(const DagArgs& a, int r, int xr, int cs, int iend, bool fin, int qa, int* done, int lane, bool patient)
 		{
 			const int fr = lane & 15, fk = lane >> 4;
 			const long lda = a.lda;
@@ -846,7 +852,7 @@ namespace gple
 				for (int q = 0; q < 4; ++q) acc[b][q] = Ct[static_cast<long>(16 * b + fk + 4 * q) * lda]; // as the previous launches left it
 			for (int i = a.c0; i < iend; ++i)
 			{
-				if (!dag_wait(a, dag_tile(a, xr, i), nullptr, dag_tile(a, r, i) + qa, lane)) return false;
+				if (!dag_wait(a, dag_tile(a, xr, i), nullptr, dag_tile(a, r, i) + qa, lane, patient)) return false;
 				const double* const Ly = a.A + static_cast<long>(r) * NB + static_cast<long>(i) * NB * lda + 16 * qa + fr;
 				const double* const Lx = a.A + static_cast<long>(xr) * NB + static_cast<long>(i) * NB * lda + fr;
 				// four chunks of 16 columns, the next one requested before the current one is multiplied (two operand sets of 40 registers)
@@ -874,7 +880,7 @@ namespace gple
 			}
 			if (fin)
 			{
-				if (!dag_wait(a, dag_t(a, cs), nullptr, nullptr, lane)) return false;
+				if (!dag_wait(a, dag_t(a, cs), nullptr, nullptr, lane, patient)) return false;
 				const double* const Tt = a.T + static_cast<long>(cs) * NB * (a.ldt + 1) + fr;
 				double xt[40];
 				[&]<int... Bs>(std::integer_sequence<int, Bs...>)
@@ -918,6 +924,86 @@ namespace gple
 			if (lane == 0) stf(done, a.epoch);
 			return true;
 		}
+		// Quarter qa of the inverse's tile (r, j), j < r, held transposed: W = V^T with V = sum_{m = j}^{r-1} L(r, m) T(m, j), then
+		// T(r, j)^T = -W T_rr^T — the same two steps as dag_task with the transposed tiles above in the place of the rows of L: rows of the
+		// accumulator = columns of T(r, j), so that every operand is read with 16 rows of 8 bytes side by side.  Out: the scratch tile (for the
+		// rows below) and the matrix T.
+		__device__ __forceinline__ bool dag_ttask(const DagArgs& a, int r, int j, int qa, int lane)
+		{
+			const int fr = lane & 15, fk = lane >> 4;
+			d4v acc[4];
+#pragma unroll
+			for (int b = 0; b < 4; ++b) acc[b] = (d4v){0.0, 0.0, 0.0, 0.0};
+			for (int m = j; m < r; ++m)
+			{
+				// the tile above: the diagonal one comes from the spine (all four words of its own flag), the others from their own quarter tasks
+				if (!dag_wait(a, dag_tile(a, r, m), m == j ? dag_tt(a, j, j) : nullptr, m == j ? nullptr : dag_tt(a, m, j) + qa, lane, true)) return false;
+				const double* const Ty = a.Tt + (static_cast<long>(m) * a.FS + j) * (NB * NB) + 16 * qa + fr;
+				const double* const Lx = a.A + static_cast<long>(r) * NB + static_cast<long>(m) * NB * a.lda + fr;
+				double y[2][4], x[2][4][4];
+				auto fetch = [&](int ch, int buf) {
+#pragma unroll
+					for (int q = 0; q < 4; ++q)
+					{
+						const int kk = 16 * ch + 4 * q + fk;
+						y[buf][q] = ldc(Ty + static_cast<long>(kk) * NB);
+#pragma unroll
+						for (int b = 0; b < 4; ++b) x[buf][b][q] = ldc(Lx + 16 * b + static_cast<long>(kk) * a.lda);
+					}
+				};
+				fetch(0, 0);
+#pragma unroll
+				for (int ch = 0; ch < 4; ++ch)
+				{
+					if (ch + 1 < 4) fetch(ch + 1, (ch + 1) & 1);
+#pragma unroll
+					for (int q = 0; q < 4; ++q)
+#pragma unroll
+						for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ch & 1][b][q], y[ch & 1][q], acc[b], 0, 0, 0);
+				}
+			}
+			if (!dag_wait(a, dag_t(a, r), nullptr, nullptr, lane, true)) return false;
+			const double* const Tt = a.T + static_cast<long>(r) * NB * (a.ldt + 1) + fr;
+			double xt[40];
+			[&]<int... Bs>(std::integer_sequence<int, Bs...>)
+			{
+				(
+					[&] {
+						constexpr int b = Bs, off = 2 * b * (b + 1);
+#pragma unroll
+						for (int q = 0; q < 4 * (b + 1); ++q) xt[off + q] = ldc(Tt + 16 * b + static_cast<long>(4 * q + fk) * a.ldt);
+					}(),
+					...);
+			}
+			(std::make_integer_sequence<int, 4>{});
+			d4v out[4];
+			[&]<int... Bs>(std::integer_sequence<int, Bs...>)
+			{
+				(
+					[&] {
+						constexpr int b = Bs, off = 2 * b * (b + 1);
+						out[b] = (d4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+						for (int q = 0; q < 4 * (b + 1); ++q) out[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xt[off + q], acc[q >> 2][q & 3], out[b], 0, 0, 0);
+					}(),
+					...);
+			}
+			(std::make_integer_sequence<int, 4>{});
+			// out[b][q] of lane (fr, fk) = T(r, j)(row 16 b + fk + 4 q, column 16 qa + fr)
+			double* const So = a.Tt + (static_cast<long>(r) * a.FS + j) * (NB * NB) + 16 * qa + fr;
+			double* const To = a.T + static_cast<long>(r) * NB + (static_cast<long>(j) * NB + 16 * qa + fr) * a.ldt;
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+#pragma unroll
+				for (int q = 0; q < 4; ++q)
+				{
+					stc(So + static_cast<long>(16 * b + fk + 4 * q) * NB, out[b][q]);
+					To[16 * b + fk + 4 * q] = out[b][q]; // read by later launches only
+				}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (lane == 0) stf(dag_tt(a, r, j) + qa, a.epoch);
+			return true;
+		}
 		// tasks of the launch, in dependency order; host and device count them the same way.  Column c of the block [c0, C1): the tiles below
 		// row c + 1 (the spine finishes (c + 1, c) itself), with the two pre-tiles of row c + 2 right after tile (c + 2, c), which they need
 		__host__ __device__ inline int dag_column_units(int c, int C1, int R, bool& has_pre, int& lo)
@@ -927,14 +1013,14 @@ namespace gple
 			const int ng = R - lo > 0 ? R - lo : 0;
 			return ng + (has_pre ? 2 : 0);
 		}
-		__host__ inline int dag_count_units(int c0, int C1, int R)
+		__host__ inline int dag_count_units(int c0, int C1, int R, bool inverse)
 		{
 			int n = 0;
 			for (int c = c0; c < C1; ++c)
 			{
 				bool hp;
 				int lo;
-				n += dag_column_units(c, C1, R, hp, lo);
+				n += dag_column_units(c, C1, R, hp, lo) + (inverse ? c : 0); // the inverse's row c (tiles (c, c - 1) .. (c, 0)) waits for T_c like column c
 			}
 			return n;
 		}
@@ -976,13 +1062,15 @@ namespace gple
 							else if (u <= 2) kind = u, r = cc + 2;
 							else kind = 0, r = cc + u;
 						}
-						u -= nu;
+						else if (a.Tt != nullptr && u < nu + cc) kind = 3, r = cc, c = cc - 1 - (u - nu); // the inverse's tile (cc, c), nearest the diagonal first
+						u -= nu + (a.Tt != nullptr ? cc : 0);
 					}
 					if (kind < 0) return;
 					bool ok;
-					if (kind == 0) ok = dag_task(a, r, c, c, c, true, qa, dag_tile(a, r, c) + qa, lane);
-					else if (kind == 1) ok = dag_task(a, r, r - 1, r - 1, r - 1, false, qa, dag_pb(a, r) + qa, lane);
-					else ok = dag_task(a, r, r, r, r - 1, false, qa, dag_pc(a, r) + qa, lane);
+					if (kind == 3) ok = dag_ttask(a, r, c, qa, lane);
+					else if (kind == 0) ok = dag_task(a, r, c, c, c, true, qa, dag_tile(a, r, c) + qa, lane, r > c + 3 && r >= a.C1 ? true : r > c + 4);
+					else if (kind == 1) ok = dag_task(a, r, r - 1, r - 1, r - 1, false, qa, dag_pb(a, r) + qa, lane, false);
+					else ok = dag_task(a, r, r, r, r - 1, false, qa, dag_pc(a, r) + qa, lane, false);
 					if (!ok) return;
 				}
 			}
@@ -1038,6 +1126,12 @@ namespace gple
 					stc(Tkk + rr + static_cast<long>(c) * a.ldt, c <= rr ? TI[rr * DLS + c] : 0.0);
 				}
 			};
+			// columns [c_lo, c_lo + nc) of T_k^T (= rows of T_k: complete with their row tile) into the scratch of the inverse's tiles
+			auto store_tt_cols = [&](int k, int c_lo, int nc) {
+				if (a.Tt == nullptr) return;
+				double* __restrict__ Td = a.Tt + (static_cast<long>(k) * a.FS + k) * (NB * NB) + lane;
+				for (int c = c_lo; c < c_lo + nc; ++c) stc(Td + static_cast<long>(c) * NB, lane <= c ? TI[c * DLS + lane] : 0.0);
+			};
 			// the block above an odd diagonal block of T: see potrf_step_kernel
 			auto zero_above = [&](int k) {
 				double* __restrict__ Tab = a.T + static_cast<long>(k) * NB * (a.ldt + 1) - NB;
@@ -1091,7 +1185,7 @@ namespace gple
 				stamp(0);
 				if (!have)
 				{
-					if (k >= a.c0 + 2 && !dag_wait(a, dag_pb(a, k), dag_pc(a, k), nullptr, lane)) break;
+					if (k >= a.c0 + 2 && nxt_ready != k && !dag_wait(a, dag_pb(a, k), dag_pc(a, k), nullptr, lane)) break; // (seen by a watcher too late to ask ahead)
 					request_inputs(k);
 				}
 				have = false;
@@ -1122,6 +1216,7 @@ namespace gple
 					if (w > 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
 					else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 					if (lane == 0) stf(dag_t(a, k - 1) + w, a.epoch);
+					store_tt_cols(k - 1, 32 + 8 * w, 8); // rows 32 .. 63 of T_{k-1}, final since the last two barriers of the round before; flagged below
 					stamp(2);
 					lds_barrier(); // everybody has read T_{k-1}: its place takes L(k, k - 1), k-major
 #pragma unroll
@@ -1140,7 +1235,8 @@ namespace gple
 						for (int c = sc0 + (w > 1); c < sc0 + scn; ++c) stc(Lg + static_cast<long>(c) * a.lda, D[c * DLS + lane]);
 					}
 					pend_upd(w, 0);
-					if (w > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					if (w > 0 || a.Tt != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					if (a.Tt != nullptr && lane == 0) stf(dag_tt(a, k - 1, k - 1) + w, a.epoch); // the wave's columns of T_{k-1}^T
 					lds_barrier();
 					if (w == 1 && lane < 4) stf(dag_tile(a, k, k - 1) + lane, a.epoch);
 				}
@@ -1194,11 +1290,22 @@ namespace gple
 				auto look = [&] {
 					if (next_in && !have && (!next_flags || nxt_ready == k + 1)) request_inputs(k + 1), have = true;
 				};
+				// wave 3 has most of the last two long stages to spare: one more look each, answer awaited, so that flags that come up during a
+				// stage are acted upon at the start of the next one
+				auto watch = [&] {
+					if (!next_in || !next_flags || have || nxt_ready == k + 1) return;
+					const int v = ldf(pre_flag_ptr(k + 1));
+					if (__all(v - a.epoch >= 0))
+					{
+						if (lane == 0) nxt_ready = k + 1;
+						request_inputs(k + 1), have = true;
+					}
+				};
 				if (w == 1) poll();
 				if (w == 0) diag_chain<2>(S, rinv, lane, first_bad);
 				else if (w == 1) diag_inv16(S, rinv, TI, 1, lane);
 				else if (w == 2) v_acc(2, 0, 0, true);
-				else v_acc(3, 0, 0, true);
+				else v_acc(3, 0, 0, true), store_tt_cols(k, 0, 16);
 				lds_barrier();
 				stamp(8);
 				if (w == 1) poll();
@@ -1212,11 +1319,12 @@ namespace gple
 				if (w > 1) look();
 				if (w == 0) diag_chain<3>(S, rinv, lane, first_bad);
 				else if (w == 1) diag_inv16(S, rinv, TI, 2, lane);
-				else if (w == 2) v_acc(2, 0, 1, false);
+				else if (w == 2) v_acc(2, 0, 1, false), store_tt_cols(k, 16, 16);
 				else
 				{
 					v_acc(3, 0, 1, false);
 					store_t_rows(k, 0, 0, 4), store_t_rows(k, 1, 0, 4); // complete since the barrier above
+					watch();
 				}
 				lds_barrier();
 				stamp(10);
@@ -1225,7 +1333,7 @@ namespace gple
 				if (w == 0) diag_inv16(S, rinv, TI, 3, lane);
 				else if (w == 1) t_fin(2, 0), v_acc(3, 0, 2, false); // LDS operations of one wave complete in order
 				else if (w == 2) t_fin(2, 1), v_acc(3, 1, 2, false);
-				else v_acc(3, 2, 2, true);
+				else v_acc(3, 2, 2, true), watch();
 				lds_barrier();
 				stamp(11);
 				look();
@@ -1236,8 +1344,10 @@ namespace gple
 				stamp(12);
 				if (k + 1 == a.C1)
 				{
+					store_tt_cols(k, 32 + 8 * w, 8);
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 					if (lane == 0) stf(dag_t(a, k) + w, a.epoch);
+					if (a.Tt != nullptr && lane == 0) stf(dag_tt(a, k, k) + w, a.epoch);
 				}
 			}
 			if (t == 0 && ldf(dag_err(a)) - a.epoch >= 0) atomicExch(a.info, -1);
@@ -1323,6 +1433,7 @@ namespace gple
 	{
 		int* flags;
 		int epoch;
+		double* tt; // scratch for the inverse's tiles when the launch forms them (chol_dag_inverse_inside), n * n doubles
 	};
 	namespace
 	{
@@ -1336,6 +1447,17 @@ namespace gple
 		}();
 		return v;
 	}
+	// Matrices of one outer block: the launch that factors them also forms T = L^-1 below the diagonal blocks — tile tasks of the same queue, every
+	// sum complete but for its last factor when the row's T_rr arrives — instead of a merge tree of GEMM launches after the last panel
+	// (n = 256 / 1024 / 2048: 25 / 50 / 90 us of the fit) and, from n = 1024 on, a second panel launch and the side stream's hand-overs.
+	static bool chol_dag_inverse_inside(int n)
+	{
+		static const bool on = [] {
+			const char* e = getenv("GPLE_CHOL_DAG_INVERSE"); // 0: the merge tree after the panels (A/B)
+			return e == nullptr || atoi(e) != 0;
+		}();
+		return on && chol_dag_scheme() && n >= 2 * NB && chol_block_bounds(n).size() == 2;
+	}
 	static int chol_dag_max_blocks()
 	{
 		static const int v = [] {
@@ -1347,7 +1469,7 @@ namespace gple
 		}();
 		return v;
 	}
-	static size_t chol_dag_flag_ints(int n) { return 4 * (static_cast<size_t>(n / NB + 4) * (n / NB) + 2); } // ticket counter, tile flags, three per column, error word
+	static size_t chol_dag_flag_ints(int n) { return 4 * (static_cast<size_t>(2 * (n / NB) + 4) * (n / NB) + 2); } // ticket counter, tile flags, three per column, error word, the inverse's tiles
 
 	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end, double* uvec,
 		const std::vector<int>* marks = nullptr, const std::function<hipError_t(int)>* on_final = nullptr, const DagState* dag = nullptr)
@@ -1393,7 +1515,8 @@ namespace gple
 				DagArgs g{};
 				g.A = A, g.lda = lda, g.T = T, g.ldt = ldt, g.info = info, g.uvec = uvec, g.flags = dag->flags + 4, g.FS = FS, g.R = R;
 				g.c0 = J0 / NB, g.C1 = Jend / NB, g.epoch = dag->epoch;
-				g.nunits = dag_count_units(g.c0, g.C1, R);
+				g.Tt = dag->tt != nullptr && J0 == 0 && Jend == n ? dag->tt : nullptr;
+				g.nunits = dag_count_units(g.c0, g.C1, R, g.Tt != nullptr);
 				g.seq = static_cast<int>(bi);
 				// once the side stream is at work (from the first mark on) the launch leaves part of the chip to its GEMMs: a workgroup of this kernel
 				// holds 70 KB of LDS on its CU whether it works or waits, which halves the GEMM workgroups that fit beside it
@@ -1540,10 +1663,11 @@ namespace gple
 		return hipSuccess;
 	}
 
-	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec, Ctx* ctx)
+	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec, Ctx* ctx, double* tt)
 	{
 		if (n % NB) return hipErrorInvalidValue;
 		DagState st{};
+		st.tt = tt;
 		const bool use_dag = ctx != nullptr && chol_dag_scheme();
 		if (use_dag)
 		{
@@ -1646,7 +1770,7 @@ namespace gple
 		if (it != cache.end()) return it->second;
 		std::vector<int> f;
 		std::vector<int> use = pct;
-		if (getenv("GPLE_CHOL_FORKS") == nullptr && n >= 8192) use.push_back(90); // a third, late fork pays from here on (9.20 vs 9.34 ms at n = 8192)
+		if (getenv("GPLE_CHOL_FORKS") == nullptr && n >= 8192 && !chol_dag_scheme()) use.push_back(90); // launch per panel: a third, late fork pays from here on (9.20 vs 9.34 ms at n = 8192; one launch per outer block: 8.96 vs 8.78)
 		int next = n; // from the last one down: the late fork matters most
 		for (auto it2 = use.rbegin(); it2 != use.rend(); ++it2)
 		{
@@ -1671,7 +1795,7 @@ namespace gple
 		if (it != cache.end()) return it->second;
 		std::vector<int> m;
 		const std::vector<int>& forks = chol_fork_points(n);
-		if (n >= chol_overlap_min_n() && n / NB >= 4 && !forks.empty())
+		if (!chol_dag_inverse_inside(n) && n >= chol_overlap_min_n() && n / NB >= 4 && !forks.empty())
 		{
 			m = forks;
 			static const bool all_cuts = [] {
@@ -1704,7 +1828,7 @@ namespace gple
 		const std::vector<int>& marks = chol_marks(n);
 		if (marks.empty())
 		{
-			w.prod = sq4(static_cast<size_t>(n));
+			w.prod = chol_dag_inverse_inside(n) ? static_cast<size_t>(n) * n : sq4(static_cast<size_t>(n)); // the transposed tiles of the inverse / one tree
 			return w;
 		}
 		size_t done = 0;
@@ -1820,6 +1944,7 @@ namespace gple
 		const std::vector<int>& marks = chol_marks(n);
 		if (marks.empty())
 		{
+			if (chol_dag_inverse_inside(n)) return potrf_lower(s, A, lda, n, T, ldt, info, uvec, ctx, work); // T complete when the launch ends
 			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info, uvec, ctx);
 			if (e != hipSuccess) return e;
 			return trtri_lower_from_diag(s, A, lda, T, ldt, n, work);

@@ -141,7 +141,7 @@ def test_panel_step_reports_a_non_positive_pivot(gpu, pend):
 
 @pytest.mark.parametrize("pre", [0, 1, 2, 3, 4, 5])
 def test_side_stream_lands_on_its_own_hardware_queue(pre):
-    """The fit's side stream (block-row inverse beside the panels, n >= 1024) must not share the main stream's hardware queue.  HIP binds
+    """The fit's side stream (block-row inverse beside the panels, matrices of more than one outer block: n >= 2560) must not share the main stream's hardware queue.  HIP binds
     streams to GPU_MAX_HW_QUEUES (4) queues by use count as they are created, so whether a fresh stream collides depends on how many streams
     the process holds already — here `pre` of them are created (and used) first, and for every count the context must end up with a side stream
     whose probe kernels ran beside the main stream's (csrc/gple_chol.hip, pick_side_stream).  Measured without the probing: N = 4096 fit
@@ -159,7 +159,7 @@ def test_side_stream_lands_on_its_own_hardware_queue(pre):
     torch.cuda.synchronize()
     api = pkg.open_api(0)
     try:
-        X, y, _, _ = config_inputs(1024, 8, 1)
+        X, y, _, _ = config_inputs(4096, 8, 1)
         f = api.real_fit(THETA_R, X, y, 3)
         assert f.scalars["info"] == 0
         attempts, overlaps = ctypes.c_int(), ctypes.c_int()

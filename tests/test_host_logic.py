@@ -247,8 +247,9 @@ def test_average_point_and_logging_writers(oracle):
 def test_factorisation_layout_rules():
     """csrc/gple_chol.hip, host logic only (gple_debug_chol_layout makes no device call): the outer blocks of the Cholesky (sized by a tile
     budget per launch) and the fork points of the block-row inverse for every padded size a fit can have — ascending multiples of 64 from 0
-    to n, no block or row group narrower than 256 columns, forks only from n = 1024 on, workspace large enough for what chol_inverse_factor
-    carves out of it (W <= n^2 / 4, two merge trees)"""
+    to n, no block or row group narrower than 256 columns; a matrix of one outer block (every n <= 2304) has no fork points — the launch that
+    factors it forms the inverse as well, in n^2 doubles of scratch —, larger ones fork, with a workspace large enough for what
+    chol_inverse_factor carves out of it (W of the rows below the first fork, two merge trees)"""
     import ctypes
     import gaussian_process_liouville_equation_amd as pkg
     lib = pkg.load_library()
@@ -267,7 +268,7 @@ def test_factorisation_layout_rules():
             assert len(bounds) == 2  # one block: every strip fits the side workgroups of a launch
         if n >= 4096:
             assert len(bounds) > 2 and np.all(np.diff(widths[:-1]) >= 0)  # the blocks widen as the trailing matrix shrinks
-        assert (len(forks) == 0) == (n < 1024)
+        assert (len(forks) == 0) == (len(bounds) == 2)
         edges = [0] + forks + [n]
         assert all(x % 64 == 0 for x in forks) and np.all(np.diff(edges) >= 256)
         # chol_inverse_factor's carve-up of the workspace follows the fork list: W of the widest row-block product, the widest side job's merge tree,
@@ -277,7 +278,7 @@ def test_factorisation_layout_rules():
             need = max(w * e for w, e in zip(groups, edges[:-1])) + max(g * g // 4 for g in groups[:-1]) + groups[-1] ** 2 // 4
             assert wd.value >= need
         else:
-            assert wd.value >= n * n // 4
+            assert wd.value >= n * n  # the transposed tiles of the inverse (potrf_dag_kernel)
 
 
 def test_factorisation_layout_with_forced_forks():
@@ -291,7 +292,7 @@ import gaussian_process_liouville_equation_amd as pkg
 lib = pkg.load_library()
 b, f = (ctypes.c_int * 512)(), (ctypes.c_int * 512)()
 nb, nf, wd = ctypes.c_int(), ctypes.c_int(), ctypes.c_ulonglong()
-for n in (1024, 4096, 8192):
+for n in (4096, 6144, 8192):
     assert lib.gple_debug_chol_layout(n, 512, b, ctypes.byref(nb), f, ctypes.byref(nf), ctypes.byref(wd)) == 0
     forks = list(f[:nf.value])
     assert len(forks) == 1 and abs(forks[0] - 0.3 * n) <= 64, forks
