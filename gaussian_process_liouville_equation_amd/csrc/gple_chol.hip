@@ -1372,6 +1372,14 @@ namespace gple
 
 	} // namespace
 
+	static bool chol_dag_scheme()
+	{
+		static const bool v = [] {
+			const char* e = getenv("GPLE_CHOL_SCHEME"); // "step": one launch per panel (rounds 2-3); "dag" (default): one launch per outer block
+			return e == nullptr || std::string(e) != "step";
+		}();
+		return v;
+	}
 	// Two-level blocking.  A 64-wide panel step that updates the WHOLE trailing matrix reads and writes it once per panel:
 	// 8 n^3 / (3 * 64) bytes in total, 2.9 GB at n = 4096 — the K = 64 updates run at HBM speed, not MFMA speed.  With outer blocks
 	// the panel steps only update the rest of their own block (a strip), and the matrix right of the block gets ONE update with
@@ -1388,7 +1396,10 @@ namespace gple
 		}();
 		static const int budget = [] {
 			const char* e = getenv("GPLE_CHOL_TILE_BUDGET");
-			return e && atoi(e) > 0 ? atoi(e) : 800;
+			if (e && atoi(e) > 0) return atoi(e);
+			// one launch per outer block: the tile tasks of a block are not bound to a panel's duration, wider blocks save trailing updates
+			// (n = 4096: 1.88 / 1.75 / 1.80 ms with 800 / 1600 / 2000; n = 8192: 8.80 / 8.43 / 8.57; one block up to n = 3648)
+			return chol_dag_scheme() ? 1600 : 800;
 		}();
 		static const bool fused = [] {
 			const char* e = getenv("GPLE_CHOL_FUSED");
@@ -1439,14 +1450,6 @@ namespace gple
 	{
 		__global__ void spin_stamp_kernel(long long* out) { if (threadIdx.x == 0) *out = wall_clock64(); }
 	} // namespace
-	static bool chol_dag_scheme()
-	{
-		static const bool v = [] {
-			const char* e = getenv("GPLE_CHOL_SCHEME"); // "step": one launch per panel (rounds 2-3); "dag" (default): one launch per outer block
-			return e == nullptr || std::string(e) != "step";
-		}();
-		return v;
-	}
 	// Matrices of one outer block: the launch that factors them also forms T = L^-1 below the diagonal blocks — tile tasks of the same queue, every
 	// sum complete but for its last factor when the row's T_rr arrives — instead of a merge tree of GEMM launches after the last panel
 	// (n = 256 / 1024 / 2048: 25 / 50 / 90 us of the fit) and, from n = 1024 on, a second panel launch and the side stream's hand-overs.

@@ -1,4 +1,4 @@
-# fork points of the block-row inverse with the one-launch factorisation (A/B through GPLE_CHOL_FORKS)
-for F in "60,80" "60,80,92" "55,75,90" "60,82,94" "50,70,85,95" "65,85" "60,80,90,96"; do
-echo "forks $F: $(GPLE_CHOL_FORKS=$F timeout -k 10 150 python probes/dag_check.py 2048 4096 8192 2>&1 | grep 'fit ' | tr '\n' ' ')"
+# where the in-kernel inverse stops paying: one outer block (budget 1600) with and without it, against two blocks (budget 800)
+for N in 2048 2560 3072 3584; do
+echo "n $N: inside $(GPLE_CHOL_TILE_BUDGET=1600 timeout -k 10 150 python probes/dag_check.py $N 2>&1 | grep 'fit ' | awk '{printf "%s ", $2}') tree $(GPLE_CHOL_TILE_BUDGET=1600 GPLE_CHOL_DAG_INVERSE=0 timeout -k 10 150 python probes/dag_check.py $N 2>&1 | grep 'fit ' | awk '{printf "%s ", $2}') budget-800 $(GPLE_CHOL_TILE_BUDGET=800 timeout -k 10 150 python probes/dag_check.py $N 2>&1 | grep 'fit ' | awk '{printf "%s ", $2}')"
 done
