@@ -796,6 +796,7 @@ namespace gple
 			int c0, C1; // the panels of this launch, an outer block of the factorisation: sums start at c0, rows below C1 are spine rows
 			int epoch, nunits, seq; // units of work (tiles: four quarter tasks each); number of this launch within the factorisation
 			long long* stamps; // probe (GPLE_CHOL_DAG_STAMPS): 8 wall-clock stamps per panel of the spine, or nullptr
+			double* pa;        // scratch, one 64 x 64 tile per block row: A~(r, r - 2) before its multiplication by T_{r-2}^T (what the pre-tiles of row r need)
 			double* Tt;        // the launch also forms T = L^-1 below the diagonal blocks (matrices of one outer block): scratch of FS x FS tiles of
 			                   // 64 x 64, tile (r, c) = T(r, c)^T (what the tiles below it multiply with), or nullptr
 		};
@@ -808,6 +809,7 @@ namespace gple
 		__device__ __forceinline__ int* dag_pb(const DagArgs& a, int k) { return a.flags + 4 * (static_cast<long>(a.R + 1) * a.FS + k); }
 		__device__ __forceinline__ int* dag_pc(const DagArgs& a, int k) { return a.flags + 4 * (static_cast<long>(a.R + 2) * a.FS + k); }
 		__device__ __forceinline__ int* dag_err(const DagArgs& a) { return a.flags + 4 * static_cast<long>(a.R + 3) * a.FS; }
+		__device__ __forceinline__ int* dag_pa(const DagArgs& a, int r) { return a.flags + 4 * (static_cast<long>(a.R + 3) * a.FS + 1 + static_cast<long>(a.FS) * a.FS + r); }
 		__device__ __forceinline__ int* dag_tt(const DagArgs& a, int r, int c) { return a.flags + 4 * (static_cast<long>(a.R + 3) * a.FS + 1 + static_cast<long>(r) * a.FS + c); }
 		// the ticket counter of the work queue: in front of the flags, at the same place whatever the matrix size — its high word outgrows every epoch
 		// and must never be read as a flag
@@ -840,7 +842,7 @@ namespace gple
 		// (fin) the result is multiplied by T_cs^T; stored in place; *done = epoch.  Accumulator element acc[b][q] of lane (fr, fk) is entry
 		// (row 16 qa + fr, column 16 b + fk + 4 q) of the tile — also the layout of the MFMA operand "row fr, k = 4 (4 b + q) + fk", so the
 		// product with T_cs^T needs no transposition.
-		__device__ __forceinline__ bool dag_task(const DagArgs& a, int r, int xr, int cs, int iend, bool fin, int qa, int* done, int lane, bool patient)
+		__device__ __forceinline__ bool dag_task(const DagArgs& a, int r, int xr, int cs, int iend, bool fin, int qa, int* done, int lane, bool patient, bool publish = false)
 		{
 			const int fr = lane & 15, fk = lane >> 4;
 			const long lda = a.lda;
@@ -877,6 +879,16 @@ namespace gple
 #pragma unroll
 						for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ch & 1][b][q], y[ch & 1][q], acc[b], 0, 0, 0);
 				}
+			}
+			if (publish) // tile (r, r - 2) of a row the spine will reach: the pre-tiles of that row form L(r, r - 2) = A~ T^T themselves, a hand-over earlier
+			{
+				double* const Pt = a.pa + static_cast<long>(r) * (NB * NB) + 16 * qa + fr;
+#pragma unroll
+				for (int b = 0; b < 4; ++b)
+#pragma unroll
+					for (int q = 0; q < 4; ++q) stc(Pt + (16 * b + fk + 4 * q) * NB, acc[b][q]);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if (lane == 0) stf(dag_pa(a, r) + qa, a.epoch);
 			}
 			if (fin)
 			{
@@ -922,6 +934,146 @@ namespace gple
 				for (int q = 0; q < 4; ++q) stc(Ct + static_cast<long>(16 * b + fk + 4 * q) * lda, acc[b][q]);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			if (lane == 0) stf(done, a.epoch);
+			return true;
+		}
+		// Quarter qa of a pre-tile of row r: (r, r - 1) (diag = false) or (r, r) — A~ = A - sum_{i <= r-2} L(r, i) L(., i)^T, stored in place for
+		// the spine.  The terms up to r - 3 as in dag_task; the last one needs L(r, r - 2) = A~(r, r - 2) T_{r-2}^T, which the wave forms itself from the
+		// published A~(r, r - 2) (its own rows; for the diagonal tile the other row blocks as well, one after the other) as soon as T_{r-2} is out
+		// instead of waiting for the tile's own task to store it: T_{r-2} -> pre-tiles -> spine is two hand-overs instead of three.
+		__device__ __forceinline__ bool dag_pre_task(const DagArgs& a, int r, bool diag, int qa, int lane, double* xch)
+		{
+			const int fr = lane & 15, fk = lane >> 4;
+			const long lda = a.lda;
+			const int cs = diag ? r : r - 1, xr = cs;
+			double* const Ct = a.A + static_cast<long>(r) * NB + static_cast<long>(cs) * NB * lda + 16 * qa + fr;
+			d4v acc[4];
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) acc[b][q] = Ct[static_cast<long>(16 * b + fk + 4 * q) * lda];
+			for (int i = a.c0; i < r - 2; ++i)
+			{
+				if (!dag_wait(a, dag_tile(a, xr, i), nullptr, dag_tile(a, r, i) + qa, lane)) return false;
+				const double* const Ly = a.A + static_cast<long>(r) * NB + static_cast<long>(i) * NB * lda + 16 * qa + fr;
+				const double* const Lx = a.A + static_cast<long>(xr) * NB + static_cast<long>(i) * NB * lda + fr;
+				double y[2][4], x[2][4][4];
+				auto fetch = [&](int ch, int buf) {
+#pragma unroll
+					for (int q = 0; q < 4; ++q)
+					{
+						const long kcol = static_cast<long>(16 * ch + 4 * q + fk) * lda;
+						y[buf][q] = ldc(Ly + kcol);
+#pragma unroll
+						for (int b = 0; b < 4; ++b) x[buf][b][q] = ldc(Lx + 16 * b + kcol);
+					}
+				};
+				fetch(0, 0);
+#pragma unroll
+				for (int ch = 0; ch < 4; ++ch)
+				{
+					if (ch + 1 < 4) fetch(ch + 1, (ch + 1) & 1);
+#pragma unroll
+					for (int q = 0; q < 4; ++q)
+#pragma unroll
+						for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ch & 1][b][q], y[ch & 1][q], acc[b], 0, 0, 0);
+				}
+			}
+			// the term of column r - 2
+			{
+				const double* const Pa = a.pa + static_cast<long>(r) * (NB * NB) + fr;
+				// rows 16 rb .. of A~(r, r - 2) in accumulator layout = operand layout (row fr, k = 16 b + fk + 4 q)
+				auto load_pa = [&](int rb, d4v (&t)[4]) {
+#pragma unroll
+					for (int b = 0; b < 4; ++b)
+#pragma unroll
+						for (int q = 0; q < 4; ++q) t[b][q] = ldc(Pa + 16 * rb + (16 * b + fk + 4 * q) * NB);
+				};
+				if (!dag_wait(a, dag_pa(a, r), nullptr, nullptr, lane)) return false; // (all four quarters; the off-diagonal tile needs its own only)
+				d4v pa_own[4];
+				load_pa(qa, pa_own);
+				if (a.stamps != nullptr && lane == 0 && qa == 0 && diag) a.stamps[16 * r + 12 + 1] = wall_clock64();
+				if (!dag_wait(a, dag_t(a, r - 2), nullptr, nullptr, lane)) return false;
+				if (a.stamps != nullptr && lane == 0 && qa == 0 && diag) a.stamps[16 * r + 12 + 2] = wall_clock64();
+				const double* const Tt = a.T + static_cast<long>(r - 2) * NB * (a.ldt + 1) + fr;
+				double xt[40];
+				[&]<int... Bs>(std::integer_sequence<int, Bs...>)
+				{
+					(
+						[&] {
+							constexpr int b = Bs, off = 2 * b * (b + 1);
+#pragma unroll
+							for (int q = 0; q < 4 * (b + 1); ++q) xt[off + q] = ldc(Tt + 16 * b + static_cast<long>(4 * q + fk) * a.ldt);
+						}(),
+						...);
+				}
+				(std::make_integer_sequence<int, 4>{});
+				// rows of L(r, r - 2) from rows of A~: out(row, j) = sum_{k <= j} in(row, k) T(j, k)
+				auto times_tt = [&](const d4v (&in)[4], d4v (&out)[4]) {
+					[&]<int... Bs>(std::integer_sequence<int, Bs...>)
+					{
+						(
+							[&] {
+								constexpr int b = Bs, off = 2 * b * (b + 1);
+								out[b] = (d4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+								for (int q = 0; q < 4 * (b + 1); ++q) out[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[off + q], in[q >> 2][q & 3], out[b], 0, 0, 0);
+							}(),
+							...);
+					}
+					(std::make_integer_sequence<int, 4>{});
+				};
+				d4v la_own[4];
+				times_tt(pa_own, la_own);
+				if (diag)
+				{
+					// A~(r, r)(rows qa, columns = rows of block b) -= L(r, r - 2)(rows qa) L(r, r - 2)(rows b)^T: the four waves of the workgroup hold the four
+					// row blocks of L(r, r - 2) and meet in LDS (a unit's four quarters run on the four waves of one workgroup, in step; an fp64 MFMA
+					// is 64 cycles — forming the other three row blocks again would cost each wave 3 us)
+#pragma unroll
+					for (int b = 0; b < 4; ++b)
+#pragma unroll
+						for (int q = 0; q < 4; ++q) xch[(16 * qa + fr) * DLS + 16 * b + fk + 4 * q] = la_own[b][q];
+					asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+					for (int b = 0; b < 4; ++b)
+					{
+						double x[16];
+#pragma unroll
+						for (int q = 0; q < 16; ++q) x[q] = xch[(16 * b + fr) * DLS + 4 * q + fk];
+#pragma unroll
+						for (int q = 0; q < 16; ++q) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[q], la_own[q >> 2][q & 3], acc[b], 0, 0, 0);
+					}
+				}
+				else
+				{
+					if (!dag_wait(a, dag_tile(a, r - 1, r - 2), nullptr, nullptr, lane)) return false; // the spine's L(r - 1, r - 2)
+					const double* const Lx = a.A + static_cast<long>(r - 1) * NB + static_cast<long>(r - 2) * NB * lda + fr;
+					double x[2][4][4];
+					auto fetch = [&](int ch, int buf) {
+#pragma unroll
+						for (int q = 0; q < 4; ++q)
+#pragma unroll
+							for (int b = 0; b < 4; ++b) x[buf][b][q] = ldc(Lx + 16 * b + static_cast<long>(16 * ch + 4 * q + fk) * lda);
+					};
+					fetch(0, 0);
+#pragma unroll
+					for (int ch = 0; ch < 4; ++ch)
+					{
+						if (ch + 1 < 4) fetch(ch + 1, (ch + 1) & 1);
+#pragma unroll
+						for (int q = 0; q < 4; ++q)
+#pragma unroll
+							for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ch & 1][b][q], la_own[ch][q], acc[b], 0, 0, 0);
+					}
+				}
+			}
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) stc(Ct + static_cast<long>(16 * b + fk + 4 * q) * lda, acc[b][q]);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (lane == 0) stf((diag ? dag_pc(a, r) : dag_pb(a, r)) + qa, a.epoch);
+			if (a.stamps != nullptr && lane == 0 && qa == 0 && diag) a.stamps[16 * r + 15] = wall_clock64();
 			return true;
 		}
 		// Quarter qa of the inverse's tile (r, j), j < r, held transposed: W = V^T with V = sum_{m = j}^{r-1} L(r, m) T(m, j), then
@@ -1028,6 +1180,8 @@ namespace gple
 		__global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a)
 		{
 			const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+			__shared__ __attribute__((aligned(16))) double S[NB * DLS];  // spine: A_kk -> L_kk (strictly lower tiles); workers: the exchange tile of a diagonal pre-tile
+			__shared__ __attribute__((aligned(16))) double TI[NB * DLS]; // spine: T_k; before the chains of panel k: L(k, k - 1), k-major (D)
 			if (blockIdx.x != 0)
 			{
 				// Units are handed out in their dependency order from one counter: whatever a unit waits for was handed out before it, to a workgroup
@@ -1068,15 +1222,12 @@ namespace gple
 					if (kind < 0) return;
 					bool ok;
 					if (kind == 3) ok = dag_ttask(a, r, c, qa, lane);
-					else if (kind == 0) ok = dag_task(a, r, c, c, c, true, qa, dag_tile(a, r, c) + qa, lane, r > c + 3 && r >= a.C1 ? true : r > c + 4);
-					else if (kind == 1) ok = dag_task(a, r, r - 1, r - 1, r - 1, false, qa, dag_pb(a, r) + qa, lane, false);
-					else ok = dag_task(a, r, r, r, r - 1, false, qa, dag_pc(a, r) + qa, lane, false);
+					else if (kind == 0) ok = dag_task(a, r, c, c, c, true, qa, dag_tile(a, r, c) + qa, lane, r > c + 3 && r >= a.C1 ? true : r > c + 4, r == c + 2 && r < a.C1);
+					else ok = dag_pre_task(a, r, kind == 2, qa, lane, S);
 					if (!ok) return;
 				}
 			}
 			// ---- the spine: four waves, the schedule of potrf_step_kernel's panel waves
-			__shared__ __attribute__((aligned(16))) double S[NB * DLS];  // A_kk -> L_kk (strictly lower tiles)
-			__shared__ __attribute__((aligned(16))) double TI[NB * DLS]; // T_k; before the chains of panel k: L(k, k - 1), k-major (D)
 			__shared__ double rinv[NB];
 			double* const D = TI;
 			const int fr = lane & 15, fk = lane >> 4;
@@ -1445,6 +1596,7 @@ namespace gple
 		int* flags;
 		int epoch;
 		double* tt; // scratch for the inverse's tiles when the launch forms them (chol_dag_inverse_inside), n * n doubles
+		double* pa; // scratch for the published pre-multiplication tiles (r, r - 2), 64 n doubles
 	};
 	namespace
 	{
@@ -1472,7 +1624,7 @@ namespace gple
 		}();
 		return v;
 	}
-	static size_t chol_dag_flag_ints(int n) { return 4 * (static_cast<size_t>(2 * (n / NB) + 4) * (n / NB) + 2); } // ticket counter, tile flags, three per column, error word, the inverse's tiles
+	static size_t chol_dag_flag_ints(int n) { return 4 * (static_cast<size_t>(2 * (n / NB) + 5) * (n / NB) + 2); } // ticket counter, tile flags, three per column, error word, the inverse's tiles, one per row
 
 	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end, double* uvec,
 		const std::vector<int>* marks = nullptr, const std::function<hipError_t(int)>* on_final = nullptr, const DagState* dag = nullptr)
@@ -1518,6 +1670,7 @@ namespace gple
 				DagArgs g{};
 				g.A = A, g.lda = lda, g.T = T, g.ldt = ldt, g.info = info, g.uvec = uvec, g.flags = dag->flags + 4, g.FS = FS, g.R = R;
 				g.c0 = J0 / NB, g.C1 = Jend / NB, g.epoch = dag->epoch;
+				g.pa = dag->pa;
 				g.Tt = dag->tt != nullptr && J0 == 0 && Jend == n ? dag->tt : nullptr;
 				g.nunits = dag_count_units(g.c0, g.C1, R, g.Tt != nullptr);
 				g.seq = static_cast<int>(bi);
@@ -1555,7 +1708,14 @@ namespace gple
 							const long long* q = h.data() + 16 * k;
 							fprintf(stderr, "  panel %3d: start %8.2f |", k, (q[0] - h[16 * 1023]) * 0.01);
 							for (int i = 1; i <= LAST_STAMP; ++i) fprintf(stderr, " %5.2f", (q[i] - q[i - 1]) * 0.01);
-							fprintf(stderr, " | step %6.2f\n", (q[LAST_STAMP] - q[0]) * 0.01);
+							fprintf(stderr, " | step %6.2f", (q[LAST_STAMP] - q[0]) * 0.01);
+							if (k >= g.c0 + 2 && q[15] != 0)
+							{
+								const long long* pq = h.data() + 16 * (k - 1);
+								fprintf(stderr, " | diagonal pre-tile of this row, after the start of the panel before: published tile seen %6.2f, T seen %6.2f, done %6.2f", (q[13] - pq[0]) * 0.01,
+									(q[14] - pq[0]) * 0.01, (q[15] - pq[0]) * 0.01);
+							}
+							fprintf(stderr, "\n");
 						}
 					}
 				}
@@ -1666,12 +1826,12 @@ namespace gple
 		return hipSuccess;
 	}
 
-	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec, Ctx* ctx, double* tt)
+	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec, Ctx* ctx, double* tt, double* pa)
 	{
 		if (n % NB) return hipErrorInvalidValue;
 		DagState st{};
-		st.tt = tt;
-		const bool use_dag = ctx != nullptr && chol_dag_scheme();
+		st.tt = tt, st.pa = pa;
+		const bool use_dag = ctx != nullptr && pa != nullptr && chol_dag_scheme();
 		if (use_dag)
 		{
 			const hipError_t e = dag_state(ctx, s, n, st);
@@ -1847,7 +2007,12 @@ namespace gple
 	size_t chol_inverse_work_doubles(int n)
 	{
 		const InvWork w = chol_inverse_work_split(n);
-		return w.prod + w.side + w.main + 64;
+		return w.prod + w.side + w.main + 64 + static_cast<size_t>(NB) * n; // the last 64 n: potrf_dag_kernel's published tiles
+	}
+	static double* chol_work_pa(double* work, int n)
+	{
+		const InvWork w = chol_inverse_work_split(n);
+		return work + w.prod + w.side + w.main + 64;
 	}
 	// 128-tile GEMMs with a triangular k-range start at their 128-aligned diagonal tile and take in the block above the second 64-block of the
 	// pair, which the panel step zeroes for GLOBALLY odd 64-blocks only: a sub-matrix whose origin is an odd multiple of 64 stays on 64-tiles
@@ -1947,8 +2112,8 @@ namespace gple
 		const std::vector<int>& marks = chol_marks(n);
 		if (marks.empty())
 		{
-			if (chol_dag_inverse_inside(n)) return potrf_lower(s, A, lda, n, T, ldt, info, uvec, ctx, work); // T complete when the launch ends
-			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info, uvec, ctx);
+			if (chol_dag_inverse_inside(n)) return potrf_lower(s, A, lda, n, T, ldt, info, uvec, ctx, work, chol_work_pa(work, n)); // T complete when the launch ends
+			hipError_t e = potrf_lower(s, A, lda, n, T, ldt, info, uvec, ctx, nullptr, chol_work_pa(work, n));
 			if (e != hipSuccess) return e;
 			return trtri_lower_from_diag(s, A, lda, T, ldt, n, work);
 		}
@@ -2015,6 +2180,7 @@ namespace gple
 			return hipSuccess;
 		};
 		DagState dst{};
+		dst.pa = chol_work_pa(work, n);
 		const bool use_dag = chol_dag_scheme();
 		if (use_dag && (e = dag_state(ctx, s, n, dst)) != hipSuccess) return e;
 		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n, uvec, &marks, &on_final, use_dag ? &dst : nullptr)) != hipSuccess) return e;

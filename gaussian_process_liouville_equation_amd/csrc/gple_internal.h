@@ -155,7 +155,7 @@ namespace gple
 	// 64 x 64 blocks, zeros above the diagonal), i.e. the diagonal blocks of T = L^-1 (potrf_diag_kernel).  info (device int): 0 or 1 + index of the
 	// first non-positive pivot.
 	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec = nullptr, Ctx* ctx = nullptr,
-		double* tt = nullptr); // tt: n * n doubles of scratch — the launch also completes T = L^-1 (one-launch scheme, one outer block)
+		double* tt = nullptr, double* pa = nullptr); // pa: 64 n doubles of scratch (without: a launch per panel); tt: n * n doubles — the launch also completes T = L^-1
 	hipError_t debug_potrf_diag(hipStream_t s, const double* A, double* T, int* info, long long* stamps);
 	void chol_layout(int n, std::vector<int>& bounds, std::vector<int>& forks, size_t& work_doubles);
 	hipError_t debug_potrf_step(hipStream_t s, double* A, long lda, double* T, long ldt, int* info, long long* stamps, int pend, int below);
