@@ -797,8 +797,10 @@ namespace gple
 			int epoch, nunits, seq; // units of work (tiles: four quarter tasks each); number of this launch within the factorisation
 			long long* stamps; // probe (GPLE_CHOL_DAG_STAMPS): 8 wall-clock stamps per panel of the spine, or nullptr
 			double* pa;        // scratch, one 64 x 64 tile per block row: A~(r, r - 2) before its multiplication by T_{r-2}^T (what the pre-tiles of row r need)
+			int tt_ld;         // tiles per row of Tt (= panels of the launch): tile (r, c) at ((r - c0) * tt_ld + (c - c0)) * 4096
 			double* Tt;        // the launch also forms T = L^-1 below the diagonal blocks (matrices of one outer block): scratch of FS x FS tiles of
-			                   // 64 x 64, tile (r, c) = T(r, c)^T (what the tiles below it multiply with), or nullptr
+			                   // 64 x 64, tile (r, c) = T(r, c)^T (what the tiles below it multiply with), or nullptr; for the launch's own columns: the whole
+			                   // inverse of a one-block matrix, the diagonal row block of T of a launch that is one row block of a larger inverse
 		};
 		__device__ __forceinline__ double ldc(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 		__device__ __forceinline__ void stc(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1086,11 +1088,11 @@ namespace gple
 			d4v acc[4];
 #pragma unroll
 			for (int b = 0; b < 4; ++b) acc[b] = (d4v){0.0, 0.0, 0.0, 0.0};
-			for (int m = j; m < r; ++m)
+			for (int m = j; m < r; ++m) // (j >= c0: the launch's own columns)
 			{
 				// the tile above: the diagonal one comes from the spine (all four words of its own flag), the others from their own quarter tasks
 				if (!dag_wait(a, dag_tile(a, r, m), m == j ? dag_tt(a, j, j) : nullptr, m == j ? nullptr : dag_tt(a, m, j) + qa, lane, true)) return false;
-				const double* const Ty = a.Tt + (static_cast<long>(m) * a.FS + j) * (NB * NB) + 16 * qa + fr;
+				const double* const Ty = a.Tt + (static_cast<long>(m - a.c0) * a.tt_ld + (j - a.c0)) * (NB * NB) + 16 * qa + fr;
 				const double* const Lx = a.A + static_cast<long>(r) * NB + static_cast<long>(m) * NB * a.lda + fr;
 				double y[2][4], x[2][4][4];
 				auto fetch = [&](int ch, int buf) {
@@ -1142,7 +1144,7 @@ namespace gple
 			}
 			(std::make_integer_sequence<int, 4>{});
 			// out[b][q] of lane (fr, fk) = T(r, j)(row 16 b + fk + 4 q, column 16 qa + fr)
-			double* const So = a.Tt + (static_cast<long>(r) * a.FS + j) * (NB * NB) + 16 * qa + fr;
+			double* const So = a.Tt + (static_cast<long>(r - a.c0) * a.tt_ld + (j - a.c0)) * (NB * NB) + 16 * qa + fr;
 			double* const To = a.T + static_cast<long>(r) * NB + (static_cast<long>(j) * NB + 16 * qa + fr) * a.ldt;
 #pragma unroll
 			for (int b = 0; b < 4; ++b)
@@ -1172,7 +1174,7 @@ namespace gple
 			{
 				bool hp;
 				int lo;
-				n += dag_column_units(c, C1, R, hp, lo) + (inverse ? c : 0); // the inverse's row c (tiles (c, c - 1) .. (c, 0)) waits for T_c like column c
+				n += dag_column_units(c, C1, R, hp, lo) + (inverse ? c - c0 : 0); // the inverse's row c (tiles (c, c - 1) .. (c, c0)) waits for T_c like column c
 			}
 			return n;
 		}
@@ -1216,8 +1218,8 @@ namespace gple
 							else if (u <= 2) kind = u, r = cc + 2;
 							else kind = 0, r = cc + u;
 						}
-						else if (a.Tt != nullptr && u < nu + cc) kind = 3, r = cc, c = cc - 1 - (u - nu); // the inverse's tile (cc, c), nearest the diagonal first
-						u -= nu + (a.Tt != nullptr ? cc : 0);
+						else if (a.Tt != nullptr && u < nu + cc - a.c0) kind = 3, r = cc, c = cc - 1 - (u - nu); // the inverse's tile (cc, c), nearest the diagonal first
+						u -= nu + (a.Tt != nullptr ? cc - a.c0 : 0);
 					}
 					if (kind < 0) return;
 					bool ok;
@@ -1280,7 +1282,7 @@ namespace gple
 			// columns [c_lo, c_lo + nc) of T_k^T (= rows of T_k: complete with their row tile) into the scratch of the inverse's tiles
 			auto store_tt_cols = [&](int k, int c_lo, int nc) {
 				if (a.Tt == nullptr) return;
-				double* __restrict__ Td = a.Tt + (static_cast<long>(k) * a.FS + k) * (NB * NB) + lane;
+				double* __restrict__ Td = a.Tt + (static_cast<long>(k - a.c0) * (a.tt_ld + 1)) * (NB * NB) + lane;
 				for (int c = c_lo; c < c_lo + nc; ++c) stc(Td + static_cast<long>(c) * NB, lane <= c ? TI[c * DLS + lane] : 0.0);
 			};
 			// the block above an odd diagonal block of T: see potrf_step_kernel
@@ -1626,6 +1628,59 @@ namespace gple
 	}
 	static size_t chol_dag_flag_ints(int n) { return 4 * (static_cast<size_t>(2 * (n / NB) + 5) * (n / NB) + 2); } // ticket counter, tile flags, three per column, error word, the inverse's tiles, one per row
 
+	static const std::vector<int>& chol_marks(int n);
+	constexpr int DAG_MAX_LATE_BLOCK = 32 * NB; // columns
+	// the launches of the one-launch scheme: outer block boundaries and marks (a block boundary closer than 256 columns to a mark gives way to it)
+	static std::vector<int> chol_dag_cuts(int n, const std::vector<int>* marks)
+	{
+		std::vector<int> cuts(chol_block_bounds(n));
+		if (marks)
+		{
+			cuts.erase(std::remove_if(cuts.begin(), cuts.end(),
+						   [&](int b) {
+							   if (b == 0 || b == n) return false;
+							   for (int m : *marks)
+								   if (b != m && std::abs(b - m) < 256) return true;
+							   // behind the first mark a row block of the inverse is one launch if it is not too wide: fewer rows below, lighter tile
+							   // tasks, and the launch can form its row block's diagonal part of T (chol_block_inverse_inside)
+							   if (!marks->empty() && b > marks->front())
+							   {
+								   int g0 = marks->front(), g1 = n;
+								   for (int m : *marks)
+								   {
+									   if (m <= b) g0 = std::max(g0, m);
+									   if (m > b) g1 = std::min(g1, m);
+								   }
+								   if (g1 - g0 <= DAG_MAX_LATE_BLOCK) return true;
+							   }
+							   return false;
+						   }),
+				cuts.end());
+			cuts.insert(cuts.end(), marks->begin(), marks->end());
+		}
+		std::sort(cuts.begin(), cuts.end());
+		cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+		return cuts;
+	}
+	// a launch [g0, g1) that is not the first and covers a whole row block of the inverse forms that row block's diagonal part of T itself (tile tasks,
+	// as for one-block matrices) instead of leaving a merge tree of GEMM launches to the side stream / to the main stream behind the last panel
+	static bool chol_block_inverse_inside(int n, int g0, int g1, const std::vector<int>& cuts)
+	{
+		static const bool on = [] {
+			const char* e = getenv("GPLE_CHOL_DAG_BLOCK_INVERSE"); // 0: merge trees (A/B)
+			return e == nullptr || atoi(e) != 0;
+		}();
+		if (!on || g0 == 0 || g1 - g0 > DAG_MAX_LATE_BLOCK) return false;
+		const std::vector<int>& marks = chol_marks(n);
+		const bool starts = std::find(marks.begin(), marks.end(), g0) != marks.end();
+		const bool ends = g1 == n || std::find(marks.begin(), marks.end(), g1) != marks.end();
+		if (!starts || !ends) return false;
+		for (int c : cuts)
+			if (c > g0 && c < g1) return false; // (cannot happen for consecutive cuts; kept for callers that pass row blocks)
+		for (int m : marks)
+			if (m > g0 && m < g1) return false;
+		return true;
+	}
 	static hipError_t potrf_columns(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, int j_begin, int j_end, double* uvec,
 		const std::vector<int>* marks = nullptr, const std::function<hipError_t(int)>* on_final = nullptr, const DagState* dag = nullptr)
 	{
@@ -1650,19 +1705,7 @@ namespace gple
 			// outer block by outer block — the marks are block boundaries too, so that a launch never continues sums another launch began —:
 			// its panels in one launch, then the matrix right of it in one update
 			const int FS = n / NB, R = FS + (uvec ? 1 : 0);
-			std::vector<int> cuts(bounds);
-			if (marks) cuts.insert(cuts.end(), marks->begin(), marks->end());
-			if (marks)
-				cuts.erase(std::remove_if(cuts.begin(), cuts.end(),
-							   [&](int b) {
-								   if (b == 0 || b == n) return false;
-								   for (int m : *marks)
-									   if (b != m && std::abs(b - m) < 256) return true; // no sliver between a block bound and a mark: the mark stays
-								   return false;
-							   }),
-					cuts.end());
-			std::sort(cuts.begin(), cuts.end());
-			cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+			const std::vector<int> cuts = chol_dag_cuts(n, marks);
 			for (size_t bi = 0; bi + 1 < cuts.size(); ++bi)
 			{
 				const int J0 = cuts[bi], Jend = cuts[bi + 1];
@@ -1671,7 +1714,10 @@ namespace gple
 				g.A = A, g.lda = lda, g.T = T, g.ldt = ldt, g.info = info, g.uvec = uvec, g.flags = dag->flags + 4, g.FS = FS, g.R = R;
 				g.c0 = J0 / NB, g.C1 = Jend / NB, g.epoch = dag->epoch;
 				g.pa = dag->pa;
-				g.Tt = dag->tt != nullptr && J0 == 0 && Jend == n ? dag->tt : nullptr;
+				// the whole inverse of a one-block matrix; otherwise the diagonal row block of T of a launch that is exactly one row block of the
+				// inverse — except the first, whose tile tasks are busy enough (chol_block_inverse_inside)
+				g.Tt = dag->tt != nullptr && ((J0 == 0 && Jend == n) || chol_block_inverse_inside(n, J0, Jend, cuts)) ? dag->tt : nullptr;
+				g.tt_ld = (Jend - J0) / NB;
 				g.nunits = dag_count_units(g.c0, g.C1, R, g.Tt != nullptr);
 				g.seq = static_cast<int>(bi);
 				// once the side stream is at work (from the first mark on) the launch leaves part of the chip to its GEMMs: a workgroup of this kernel
@@ -1980,14 +2026,14 @@ namespace gple
 	}
 	struct InvWork
 	{
-		size_t prod, side, main;
+		size_t prod, side, main, tt;
 	};
 	// prod: W(rows below the first mark, columns left of the last one), accumulated block row by block row (chol_inverse_factor); side / main: the
 	// merge trees of the widest side job / of the last row block (b^2 / 4 doubles for b columns); without marks one tree over all n columns
 	static InvWork chol_inverse_work_split(int n)
 	{
 		const auto sq4 = [](size_t b) { return b * b / 4; };
-		InvWork w{0, 0, 0};
+		InvWork w{0, 0, 0, 0};
 		const std::vector<int>& marks = chol_marks(n);
 		if (marks.empty())
 		{
@@ -2002,12 +2048,28 @@ namespace gple
 		}
 		w.prod = (static_cast<size_t>(n) - marks.front()) * static_cast<size_t>(marks.back());
 		w.main = sq4(static_cast<size_t>(n) - done);
+		if (chol_dag_scheme()) // row blocks whose launch forms their diagonal part of T: transposed tiles of the widest one
+		{
+			const std::vector<int> cuts = chol_dag_cuts(n, &marks);
+			int g0 = 0;
+			for (size_t i = 0; i <= marks.size(); ++i)
+			{
+				const int g1 = i < marks.size() ? marks[i] : n;
+				if (chol_block_inverse_inside(n, g0, g1, cuts)) w.tt = std::max(w.tt, static_cast<size_t>(g1 - g0) * (g1 - g0));
+				g0 = g1;
+			}
+		}
 		return w;
 	}
 	size_t chol_inverse_work_doubles(int n)
 	{
 		const InvWork w = chol_inverse_work_split(n);
-		return w.prod + w.side + w.main + 64 + static_cast<size_t>(NB) * n; // the last 64 n: potrf_dag_kernel's published tiles
+		return w.prod + w.side + w.main + 64 + static_cast<size_t>(NB) * n + w.tt; // 64 n: potrf_dag_kernel's published tiles; then its transposed tiles
+	}
+	static double* chol_work_tt(double* work, int n)
+	{
+		const InvWork w = chol_inverse_work_split(n);
+		return w.tt ? work + w.prod + w.side + w.main + 64 + static_cast<size_t>(NB) * n : nullptr;
 	}
 	static double* chol_work_pa(double* work, int n)
 	{
@@ -2168,12 +2230,14 @@ namespace gple
 		};
 		int done = 0;
 		size_t nfork = 0;
+		const bool use_dag = chol_dag_scheme();
+		const std::vector<int> dag_cuts = use_dag ? chol_dag_cuts(n, &marks) : std::vector<int>{};
 		const std::function<hipError_t(int)> on_final = [&](int j) -> hipError_t {
 			hipError_t er;
 			hipEvent_t ev = ctx->side_forks[nfork++];
 			if ((er = hipEventRecord(ev, s)) != hipSuccess) return er;
 			if ((er = hipStreamWaitEvent(side, ev, 0)) != hipSuccess) return er;
-			if ((er = tree(side, done, j, w_side)) != hipSuccess) return er;
+			if (!(use_dag && chol_block_inverse_inside(n, done, j, dag_cuts)) && (er = tree(side, done, j, w_side)) != hipSuccess) return er; // (else: formed by the block's launch)
 			if (done > 0 && (er = t_product(side, done, j)) != hipSuccess) return er;
 			if ((er = w_accumulate(side, done, j)) != hipSuccess) return er;
 			done = j;
@@ -2181,12 +2245,12 @@ namespace gple
 		};
 		DagState dst{};
 		dst.pa = chol_work_pa(work, n);
-		const bool use_dag = chol_dag_scheme();
+		dst.tt = chol_work_tt(work, n);
 		if (use_dag && (e = dag_state(ctx, s, n, dst)) != hipSuccess) return e;
 		if ((e = potrf_columns(s, A, lda, n, T, ldt, info, 0, n, uvec, &marks, &on_final, use_dag ? &dst : nullptr)) != hipSuccess) return e;
 		if ((e = hipEventRecord(ctx->side_join, side)) != hipSuccess) return e;
-		// the last row block: its tree does not need the side's results, the last product does
-		if ((e = tree(s, done, n, w_main)) != hipSuccess) return e;
+		// the last row block: its tree (unless its launch formed it) does not need the side's results, the last product does
+		if (!(use_dag && chol_block_inverse_inside(n, done, n, dag_cuts)) && (e = tree(s, done, n, w_main)) != hipSuccess) return e;
 		if ((e = hipStreamWaitEvent(s, ctx->side_join, 0)) != hipSuccess) return e;
 		return t_product(s, done, n);
 	}
