@@ -222,3 +222,25 @@ def test_work_queue_makes_progress_with_one_worker_workgroup():
     workgroups running (the situation of a chip shared with other work): here one worker workgroup beside the spine (GPLE_CHOL_DAG_BLOCKS=2) —
     4096 / 64 = 64 panels, four launches, about 60 ms instead of 2"""
     _fit_in_own_process({"GPLE_CHOL_DAG_BLOCKS": "2"}, (1024, 4096))
+
+
+def test_repeated_fits_agree_bit_for_bit(gpu):
+    """every tile of the factorisation is summed in a fixed order whatever the timing of its hand-overs (potrf_dag_kernel), so repeated fits of the same
+    inputs must agree BIT FOR BIT — any difference is a race (a tile read before it was final, a stale line).  Sizes interleaved, so that the words of the
+    never-cleared flag buffer change their meaning from fit to fit; one- and several-block matrices, real and complex (probes/dag_soak.py: 49 500 fits, alone
+    and beside another process, none differed)."""
+    from gaussian_process_liouville_equation_amd import _capi as c
+    from tests.test_gpu_configs import config_inputs, THETA_R, THETA_C
+    cases = [(False, N) for N in (256, 640, 1024, 2048, 3072, 4096)] + [(True, 256), (True, 1024)]
+    inputs = {k: config_inputs(k[1], 8, 1, cplx=k[0]) for k in cases}
+    ref = {}
+    for r in range(12):
+        order = list(cases)
+        np.random.default_rng(r).shuffle(order)
+        for k in order:
+            X, y, _, _ = inputs[k]
+            f = (gpu.complex_fit if k[0] else gpu.real_fit)(THETA_C if k[0] else THETA_R, X, y, 3)
+            sig = (f.scalars["info"], f.scalars["error"], f.get(c.C_INVLBL if k[0] else c.R_INVLBL).tobytes())
+            f.release()
+            assert sig[0] == 0
+            assert ref.setdefault(k, sig) == sig, (k, r)
