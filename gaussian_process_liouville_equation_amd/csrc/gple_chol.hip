@@ -3,9 +3,11 @@
 // Replaces the reference's Eigen::LDLT + solve(Identity) (kernel.cpp:281-283; complex_kernel.cpp:264-266).
 // The kernel matrices of this path are SPD by construction (sf^2 sn^2 ridge, opt.cpp:27), and Eigen's LDLT picks
 // its pivots from the not-yet-updated diagonal, which is constant here — i.e. the reference itself runs
-// unpivoted.  We therefore factor K = L L^T (right-looking, 64-wide panels, one launch per panel step; the diagonal blocks leave
-// the panel step already inverted), form T = L^-1 by block rows beside the factorisation (merge trees of MFMA GEMMs over the diagonal
-// blocks, two triangular-k products per row block), and only on request W = K^-1 = T^T T.  A non-positive pivot does not abort: sqrt() yields
+// unpivoted.  We therefore factor K = L L^T in 64-wide panels whose diagonal blocks leave their panel already inverted — by default all panels of
+// an outer block in ONE launch (potrf_dag_kernel: a spine workgroup walking down the diagonal + tile tasks from a work queue, handed over by
+// flags; GPLE_CHOL_SCHEME=step: right-looking, one launch per panel, potrf_step_kernel) —, form T = L^-1 in that same launch for matrices of one
+// outer block, by block rows beside the factorisation for larger ones (GEMMs on a side stream; the diagonal part of a row block by its own
+// launch or by a merge tree of MFMA GEMMs), and only on request W = K^-1 = T^T T.  A non-positive pivot does not abort: sqrt() yields
 // NaN which propagates into every output, and *info records the first offending column (reference behaviour:
 // LDLT::info() is never checked, NaN/Inf are clamped later by opt.cpp:420-431).
 #include <algorithm>
