@@ -813,17 +813,19 @@ namespace gple
 		__device__ __forceinline__ int* dag_pb(const DagArgs& a, int k) { return a.flags + 4 * (static_cast<long>(a.R + 1) * a.FS + k); }
 		__device__ __forceinline__ int* dag_pc(const DagArgs& a, int k) { return a.flags + 4 * (static_cast<long>(a.R + 2) * a.FS + k); }
 		__device__ __forceinline__ int* dag_err(const DagArgs& a) { return a.flags + 4 * static_cast<long>(a.R + 3) * a.FS; }
+		__device__ __forceinline__ int* dag_pb2(const DagArgs& a, int k) { return a.flags + 4 * (static_cast<long>(a.R + 3) * a.FS + 1 + static_cast<long>(a.FS) * a.FS + a.FS + k); }
 		__device__ __forceinline__ int* dag_pa(const DagArgs& a, int r) { return a.flags + 4 * (static_cast<long>(a.R + 3) * a.FS + 1 + static_cast<long>(a.FS) * a.FS + r); }
 		__device__ __forceinline__ int* dag_tt(const DagArgs& a, int r, int c) { return a.flags + 4 * (static_cast<long>(a.R + 3) * a.FS + 1 + static_cast<long>(r) * a.FS + c); }
 		// the ticket counter of the work queue: in front of the flags, at the same place whatever the matrix size — its high word outgrows every epoch
 		// and must never be read as a flag
 		__device__ __forceinline__ unsigned long long* dag_tickets(const DagArgs& a) { return reinterpret_cast<unsigned long long*>(a.flags - 4); }
 		// the whole wave waits until the four quarter flags at f4 and (if given) the four at g4 and the single flag at f1 carry this epoch
-		__device__ __forceinline__ bool dag_wait(const DagArgs& a, const int* f4, const int* g4, const int* f1, int lane, bool patient = false)
+		__device__ __forceinline__ bool dag_wait(const DagArgs& a, const int* f4, const int* g4, const int* f1, int lane, bool patient = false, const int* h4 = nullptr)
 		{
 			const int* p = f4 + (lane & 3);
 			if (g4 != nullptr && (lane & 4)) p = g4 + (lane & 3);
-			if (f1 != nullptr && lane >= 8) p = f1;
+			if (h4 != nullptr && (lane & 8)) p = h4 + (lane & 3);
+			if (f1 != nullptr && lane >= 16) p = f1;
 			const int* const err = dag_err(a);
 			for (int it = 0; it < DAG_POLL_LIMIT; ++it)
 			{
@@ -944,23 +946,28 @@ namespace gple
 		// the spine.  The terms up to r - 3 as in dag_task; the last one needs L(r, r - 2) = A~(r, r - 2) T_{r-2}^T, which the wave forms itself from the
 		// published A~(r, r - 2) (its own rows; for the diagonal tile the other row blocks as well, one after the other) as soon as T_{r-2} is out
 		// instead of waiting for the tile's own task to store it: T_{r-2} -> pre-tiles -> spine is two hand-overs instead of three.
-		__device__ __forceinline__ bool dag_pre_task(const DagArgs& a, int r, bool diag, int qa, int lane, double* xch)
+		// The off-diagonal tile comes in two halves of 32 columns (half = 0 / 1; -1: the diagonal tile, whole): its last term can only start when the
+		// spine's L(r - 1, r - 2) is out, and half the columns are half the operand loads and MFMAs between that flag and the tile's own.
+		template <int HALF>
+		__device__ __forceinline__ bool dag_pre_task(const DagArgs& a, int r, int qa, int lane, double* xch)
 		{
+			constexpr bool diag = HALF < 0;
+			constexpr int B0 = diag ? 0 : 2 * HALF, NBK = diag ? 4 : 2; // the tile's 16-column blocks B0 .. B0 + NBK - 1
 			const int fr = lane & 15, fk = lane >> 4;
 			const long lda = a.lda;
 			const int cs = diag ? r : r - 1, xr = cs;
 			double* const Ct = a.A + static_cast<long>(r) * NB + static_cast<long>(cs) * NB * lda + 16 * qa + fr;
-			d4v acc[4];
+			d4v acc[NBK];
 #pragma unroll
-			for (int b = 0; b < 4; ++b)
+			for (int b = 0; b < NBK; ++b)
 #pragma unroll
-				for (int q = 0; q < 4; ++q) acc[b][q] = Ct[static_cast<long>(16 * b + fk + 4 * q) * lda];
+				for (int q = 0; q < 4; ++q) acc[b][q] = Ct[static_cast<long>(16 * (B0 + b) + fk + 4 * q) * lda];
 			for (int i = a.c0; i < r - 2; ++i)
 			{
 				if (!dag_wait(a, dag_tile(a, xr, i), nullptr, dag_tile(a, r, i) + qa, lane)) return false;
 				const double* const Ly = a.A + static_cast<long>(r) * NB + static_cast<long>(i) * NB * lda + 16 * qa + fr;
-				const double* const Lx = a.A + static_cast<long>(xr) * NB + static_cast<long>(i) * NB * lda + fr;
-				double y[2][4], x[2][4][4];
+				const double* const Lx = a.A + static_cast<long>(xr) * NB + static_cast<long>(i) * NB * lda + 16 * B0 + fr;
+				double y[2][4], x[2][NBK][4];
 				auto fetch = [&](int ch, int buf) {
 #pragma unroll
 					for (int q = 0; q < 4; ++q)
@@ -968,7 +975,7 @@ namespace gple
 						const long kcol = static_cast<long>(16 * ch + 4 * q + fk) * lda;
 						y[buf][q] = ldc(Ly + kcol);
 #pragma unroll
-						for (int b = 0; b < 4; ++b) x[buf][b][q] = ldc(Lx + 16 * b + kcol);
+						for (int b = 0; b < NBK; ++b) x[buf][b][q] = ldc(Lx + 16 * b + kcol);
 					}
 				};
 				fetch(0, 0);
@@ -979,7 +986,7 @@ namespace gple
 #pragma unroll
 					for (int q = 0; q < 4; ++q)
 #pragma unroll
-						for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ch & 1][b][q], y[ch & 1][q], acc[b], 0, 0, 0);
+						for (int b = 0; b < NBK; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ch & 1][b][q], y[ch & 1][q], acc[b], 0, 0, 0);
 				}
 			}
 			// the term of column r - 2
@@ -1028,7 +1035,7 @@ namespace gple
 				};
 				d4v la_own[4];
 				times_tt(pa_own, la_own);
-				if (diag)
+				if constexpr (diag)
 				{
 					// A~(r, r)(rows qa, columns = rows of block b) -= L(r, r - 2)(rows qa) L(r, r - 2)(rows b)^T: the four waves of the workgroup hold the four
 					// row blocks of L(r, r - 2) and meet in LDS (a unit's four quarters run on the four waves of one workgroup, in step; an fp64 MFMA
@@ -1051,13 +1058,13 @@ namespace gple
 				else
 				{
 					if (!dag_wait(a, dag_tile(a, r - 1, r - 2), nullptr, nullptr, lane)) return false; // the spine's L(r - 1, r - 2)
-					const double* const Lx = a.A + static_cast<long>(r - 1) * NB + static_cast<long>(r - 2) * NB * lda + fr;
-					double x[2][4][4];
+					const double* const Lx = a.A + static_cast<long>(r - 1) * NB + static_cast<long>(r - 2) * NB * lda + 16 * B0 + fr;
+					double x[2][NBK][4];
 					auto fetch = [&](int ch, int buf) {
 #pragma unroll
 						for (int q = 0; q < 4; ++q)
 #pragma unroll
-							for (int b = 0; b < 4; ++b) x[buf][b][q] = ldc(Lx + 16 * b + static_cast<long>(16 * ch + 4 * q + fk) * lda);
+							for (int b = 0; b < NBK; ++b) x[buf][b][q] = ldc(Lx + 16 * b + static_cast<long>(16 * ch + 4 * q + fk) * lda);
 					};
 					fetch(0, 0);
 #pragma unroll
@@ -1067,16 +1074,16 @@ namespace gple
 #pragma unroll
 						for (int q = 0; q < 4; ++q)
 #pragma unroll
-							for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ch & 1][b][q], la_own[ch][q], acc[b], 0, 0, 0);
+							for (int b = 0; b < NBK; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ch & 1][b][q], la_own[ch][q], acc[b], 0, 0, 0);
 					}
 				}
 			}
 #pragma unroll
-			for (int b = 0; b < 4; ++b)
+			for (int b = 0; b < NBK; ++b)
 #pragma unroll
-				for (int q = 0; q < 4; ++q) stc(Ct + static_cast<long>(16 * b + fk + 4 * q) * lda, acc[b][q]);
+				for (int q = 0; q < 4; ++q) stc(Ct + static_cast<long>(16 * (B0 + b) + fk + 4 * q) * lda, acc[b][q]);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (lane == 0) stf((diag ? dag_pc(a, r) : dag_pb(a, r)) + qa, a.epoch);
+			if (lane == 0) stf((diag ? dag_pc(a, r) : HALF == 0 ? dag_pb(a, r) : dag_pb2(a, r)) + qa, a.epoch);
 			if (a.stamps != nullptr && lane == 0 && qa == 0 && diag) a.stamps[16 * r + 15] = wall_clock64();
 			return true;
 		}
@@ -1167,7 +1174,7 @@ namespace gple
 			lo = c + 1 < C1 ? c + 2 : c + 1;
 			has_pre = c + 2 < C1;
 			const int ng = R - lo > 0 ? R - lo : 0;
-			return ng + (has_pre ? 2 : 0);
+			return ng + (has_pre ? 3 : 0);
 		}
 		__host__ inline int dag_count_units(int c0, int C1, int R, bool inverse)
 		{
@@ -1205,7 +1212,7 @@ namespace gple
 					__syncthreads();
 					if (u >= a.nunits) return;
 					const int qa = w;
-					// kind 0: tile (r, c) to the end; 1: pre-tile (r, r - 1); 2: pre-tile (r, r)
+					// kind 0: tile (r, c) to the end; 1, 2: halves of pre-tile (r, r - 1); 3: pre-tile (r, r); 4: a tile of the inverse
 					int kind = -1, r = 0, c = 0;
 					for (int cc = a.c0; kind < 0 && cc < a.C1; ++cc)
 					{
@@ -1217,17 +1224,19 @@ namespace gple
 							c = cc;
 							if (!hp) kind = 0, r = lo + u;
 							else if (u == 0) kind = 0, r = cc + 2;
-							else if (u <= 2) kind = u, r = cc + 2;
-							else kind = 0, r = cc + u;
+							else if (u <= 3) kind = u, r = cc + 2; // 1, 2: the halves of pre-tile (r, r - 1); 3: pre-tile (r, r)
+							else kind = 0, r = cc + u - 1;
 						}
-						else if (a.Tt != nullptr && u < nu + cc - a.c0) kind = 3, r = cc, c = cc - 1 - (u - nu); // the inverse's tile (cc, c), nearest the diagonal first
+						else if (a.Tt != nullptr && u < nu + cc - a.c0) kind = 4, r = cc, c = cc - 1 - (u - nu); // the inverse's tile (cc, c), nearest the diagonal first
 						u -= nu + (a.Tt != nullptr ? cc - a.c0 : 0);
 					}
 					if (kind < 0) return;
 					bool ok;
-					if (kind == 3) ok = dag_ttask(a, r, c, qa, lane);
+					if (kind == 4) ok = dag_ttask(a, r, c, qa, lane);
 					else if (kind == 0) ok = dag_task(a, r, c, c, c, true, qa, dag_tile(a, r, c) + qa, lane, r > c + 3 && r >= a.C1 ? true : r > c + 4, r == c + 2 && r < a.C1);
-					else ok = dag_pre_task(a, r, kind == 2, qa, lane, S);
+					else if (kind == 1) ok = dag_pre_task<0>(a, r, qa, lane, S);
+					else if (kind == 2) ok = dag_pre_task<1>(a, r, qa, lane, S);
+					else ok = dag_pre_task<-1>(a, r, qa, lane, S);
 					if (!ok) return;
 				}
 			}
@@ -1306,12 +1315,23 @@ namespace gple
 			// A~(k, k): waves 1-3, a row per lane (512 contiguous bytes per load: anything less is a gather to the address unit, ~60 cycles an instruction),
 			// 21 or 22 columns per wave; the 8-way bank conflict on the way into S is the lesser evil.  Wave 0 loads none: its issue slots belong to the
 			// chains.  A~(k, k - 1): row tile w as operand fragments, every wave (gathers: 16 rows x 4 columns each).
-			double sreg[22], bx[16];
+			double sreg[14], bx[16];
 			bool have = false;        // ... already requested for the coming panel
 			__shared__ int nxt_ready; // wave 1 watches the flags of the coming panel's pre-tiles for everybody
 			if (t == 0) nxt_ready = -1;
-			const int sc0 = 21 * (w - 1); // 22 columns per wave (waves 1 / 2 and 2 / 3 share one): the same count everywhere, for the s_waitcnt below
-			constexpr int scn = 22;
+			// A~(k, k), lower tiles only, by waves 1-3: tile column 0 — all the first chain needs — a 64-row column per instruction (column c belongs to
+			// wave 1 + c % 3: sreg[0 .. sj16)), written to S before the chain; and each wave's own two tiles of the stage beside the first chain
+			// (wave 1: (1,1), (2,1); wave 2: (2,2), (3,2); wave 3: (3,1), (3,3): sreg[6 .. 14)), which it writes at the start of that stage itself —
+			// nobody else reads them before the barrier that ends it.  L(k, k - 1) leaves by the same column ownership (all 64 columns).
+			const int sjn = w == 1 ? 22 : 21, sj16 = w == 1 ? 6 : 5;
+			// element j (0 .. 7) of the wave's two tiles: row and column in the block
+			auto own_row = [&](int j) { const int e = lane + 64 * j; return w == 3 ? 48 + (e & 15) : 16 * w + (e & 31); };
+			auto own_col = [&](int j) {
+				const int e = lane + 64 * j;
+				if (w != 3) return 16 * w + (e >> 5);
+				const int cc = e >> 4;
+				return cc < 16 ? 16 + cc : 32 + cc;
+			};
 			// A~(k, k - 1) is asked for a stage or two ahead (the panel's first product needs it at once); A~(k, k) at the top of the panel — it is not
 			// needed before that product and two barriers are through, and 44 registers less live through the chains
 			auto request_inputs = [&](int k) {
@@ -1325,11 +1345,16 @@ namespace gple
 			auto request_diag = [&](int k) {
 				const double* __restrict__ Akk = a.A + static_cast<long>(k) * NB * (a.lda + 1);
 				if (w > 0)
+				{
 #pragma unroll
-					for (int q = 0; q < 22; ++q) sreg[q] = ldc(Akk + lane + static_cast<long>(sc0 + q) * a.lda);
+					for (int q = 0; q < 6; ++q)
+						if (q < sj16) sreg[q] = ldc(Akk + lane + static_cast<long>(w - 1 + 3 * q) * a.lda);
+#pragma unroll
+					for (int j = 0; j < 8; ++j) sreg[6 + j] = ldc(Akk + own_row(j) + static_cast<long>(own_col(j)) * a.lda);
+				}
 			};
-			// the eight flags of the two pre-tiles of row k, one per lane (the rest repeat them)
-			auto pre_flag_ptr = [&](int k) { return (lane & 4 ? dag_pc(a, k) : dag_pb(a, k)) + (lane & 3); };
+			// the twelve flags of the pre-tiles of row k (two halves of (k, k - 1), (k, k)), one per lane (the rest repeat them)
+			auto pre_flag_ptr = [&](int k) { return (lane & 8 ? dag_pc(a, k) : lane & 4 ? dag_pb2(a, k) : dag_pb(a, k)) + (lane & 3); };
 			for (int k = a.c0; k < a.C1; ++k)
 			{
 				const int j0 = k * NB;
@@ -1340,7 +1365,7 @@ namespace gple
 				stamp(0);
 				if (!have)
 				{
-					if (k >= a.c0 + 2 && nxt_ready != k && !dag_wait(a, dag_pb(a, k), dag_pc(a, k), nullptr, lane)) break; // (seen by a watcher too late to ask ahead)
+					if (k >= a.c0 + 2 && nxt_ready != k && !dag_wait(a, dag_pb(a, k), dag_pb2(a, k), nullptr, lane, false, dag_pc(a, k))) break; // (seen by a watcher too late to ask ahead)
 					request_inputs(k);
 				}
 				have = false;
@@ -1367,35 +1392,38 @@ namespace gple
 							...);
 					}
 					(std::make_integer_sequence<int, 4>{});
-					// T_{k-1}: the wave's stores are a product and a stage old; only the 22 loads of A~(k, k) are younger
-					if (w > 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-					else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-					if (lane == 0) stf(dag_t(a, k - 1) + w, a.epoch);
 					store_tt_cols(k - 1, 32 + 8 * w, 8); // rows 32 .. 63 of T_{k-1}, final since the last two barriers of the round before; flagged below
 					stamp(2);
 					lds_barrier(); // everybody has read T_{k-1}: its place takes L(k, k - 1), k-major
 #pragma unroll
 					for (int j = 0; j < 4; ++j) tile_store_t(D + j * 16 * DLS + w * 16, lo[j], lane);
 				}
-				if (w > 0)
+				if (w > 0) // tile column 0 now, the rest in the next stage (nothing before the first chain reads it)
 #pragma unroll
-					for (int q = 0; q < 22; ++q) S[lane * DLS + sc0 + q] = sreg[q];
+					for (int q = 0; q < 6; ++q)
+						if (q < sj16) S[lane * DLS + w - 1 + 3 * q] = sreg[q];
 				lds_barrier();
 				if (pend)
 				{
-					// L(k, k - 1) leaves from D, a column (64 contiguous rows) per instruction, waves 1-3; flagged by wave 1 once all three have waited
+					// T_{k-1} (and its transposed copy): the wave's stores are a product, two barriers and more old, the loads of A~(k, k) — the only
+					// younger accesses — have been used: no waiting here
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					if (lane == 0) stf(dag_t(a, k - 1) + w, a.epoch);
+					if (a.Tt != nullptr && lane == 0) stf(dag_tt(a, k - 1, k - 1) + w, a.epoch);
+					// L(k, k - 1) leaves from D, a column (64 contiguous rows) per instruction, waves 1-3; each flags its columns after the next stage, after a
+					// wait of its own that finds the stores a chain old — the tile is only ever read whole (all four words), as the second factor of a product
 					if (w > 0)
 					{
 						double* __restrict__ Lg = a.A + j0 + lane + static_cast<long>(j0 - NB) * a.lda;
-						for (int c = sc0 + (w > 1); c < sc0 + scn; ++c) stc(Lg + static_cast<long>(c) * a.lda, D[c * DLS + lane]);
+						for (int q = 0; q < sjn; ++q) stc(Lg + static_cast<long>(w - 1 + 3 * q) * a.lda, D[(w - 1 + 3 * q) * DLS + lane]);
 					}
 					pend_upd(w, 0);
-					if (w > 0 || a.Tt != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-					if (a.Tt != nullptr && lane == 0) stf(dag_tt(a, k - 1, k - 1) + w, a.epoch); // the wave's columns of T_{k-1}^T
 					lds_barrier();
-					if (w == 1 && lane < 4) stf(dag_tile(a, k, k - 1) + lane, a.epoch);
 				}
 				stamp(3);
+				if (w > 0) // the wave's own two tiles of this stage
+#pragma unroll
+					for (int j = 0; j < 8; ++j) S[own_row(j) * DLS + own_col(j)] = sreg[6 + j];
 				if (w == 0) diag_chain<0>(S, rinv, lane, first_bad);
 				else if (pend)
 				{
@@ -1405,6 +1433,12 @@ namespace gple
 				}
 				lds_barrier();
 				stamp(4);
+				if (w > 0 && pend)
+				{
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					if (lane == 0) stf(dag_tile(a, k, k - 1) + w, a.epoch);
+					if (w == 1 && lane == 1) stf(dag_tile(a, k, k - 1), a.epoch);
+				}
 				if (w == 0) upd(1, 1, 0);
 				else if (w == 1) upd(2, 1, 0);
 				else if (w == 2) upd(3, 1, 0);
@@ -1628,7 +1662,7 @@ namespace gple
 		}();
 		return v;
 	}
-	static size_t chol_dag_flag_ints(int n) { return 4 * (static_cast<size_t>(2 * (n / NB) + 5) * (n / NB) + 2); } // ticket counter, tile flags, three per column, error word, the inverse's tiles, one per row
+	static size_t chol_dag_flag_ints(int n) { return 4 * (static_cast<size_t>(2 * (n / NB) + 6) * (n / NB) + 2); } // ticket counter, tile flags, three per column, error word, the inverse's tiles, one per row
 
 	static const std::vector<int>& chol_marks(int n);
 	constexpr int DAG_MAX_LATE_BLOCK = 32 * NB; // columns
