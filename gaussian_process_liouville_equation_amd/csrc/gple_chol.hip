@@ -1903,6 +1903,18 @@ namespace gple
 			ctx->dag_flags_ints = need;
 			ctx->dag_epoch = 0;
 		}
+		// epochs are compared as ints and multiplied by 64 in the high word of the ticket counter: long before either runs out (2^24 factorisations
+		// of one context) the buffer is cleared — in stream order, like everything that uses it — and the count starts again
+		static const int epoch_limit = [] {
+			const char* e = getenv("GPLE_CHOL_DAG_EPOCH_LIMIT"); // (tests)
+			return e && atoi(e) > 0 ? atoi(e) : 1 << 24;
+		}();
+		if (ctx->dag_epoch >= epoch_limit)
+		{
+			const hipError_t e = hipMemsetAsync(ctx->dag_flags, 0, ctx->dag_flags_ints * sizeof(int), s);
+			if (e != hipSuccess) return e;
+			ctx->dag_epoch = 0;
+		}
 		st.flags = ctx->dag_flags;
 		st.epoch = ++ctx->dag_epoch;
 		return hipSuccess;

@@ -244,3 +244,10 @@ def test_repeated_fits_agree_bit_for_bit(gpu):
             f.release()
             assert sig[0] == 0
             assert ref.setdefault(k, sig) == sig, (k, r)
+
+
+def test_flag_epochs_start_over():
+    """the flags of the one-launch factorisation are never cleared between fits, every fit takes a new epoch; the count starts over (buffer cleared in
+    stream order) long before it could run out — here after every third fit (GPLE_CHOL_DAG_EPOCH_LIMIT=3): twelve fits of changing sizes, each
+    with the fit's identities"""
+    _fit_in_own_process({"GPLE_CHOL_DAG_EPOCH_LIMIT": "3"}, (1024, 4096, 512, 2304, 4096, 1024, 256, 4096, 3072, 1024, 2560, 512))
