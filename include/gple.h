@@ -68,7 +68,8 @@ typedef struct gple_real_fit_scalars {
 	double error_derivative[4];      /* get_error_derivative          kernel.cpp:381-400           */
 	double population_derivative[4]; /* get_population_derivative     kernel.cpp:401-435           */
 	double purity_derivative[4];     /* get_purity_derivative         kernel.cpp:436-477           */
-	int info;                        /* 0: factorisation fine; k>0: non-positive pivot met at column k */
+	int info;                        /* 0: factorisation fine; k>0: non-positive pivot met at column k; -1: a workgroup of the factorisation gave up
+	                                    waiting for another (2^21 polls, about a second: a GPU held by other work for that long) — results invalid */
 } gple_real_fit_scalars;
 
 /* Scalar getters of TrainingComplexKernel. */
@@ -79,7 +80,7 @@ typedef struct gple_complex_fit_scalars {
 	double purity;               /* complex_kernel.cpp:357-377   */
 	double error_derivative[8];  /* complex_kernel.cpp:444-474   */
 	double purity_derivative[8]; /* complex_kernel.cpp:475-590   */
-	int info;
+	int info;                    /* as in gple_real_fit_scalars  */
 } gple_complex_fit_scalars;
 
 /* Scalar getters of PredictiveKernel / PredictiveComplexKernel (only the first 4 entries of
