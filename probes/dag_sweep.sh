@@ -1,7 +1,4 @@
-# tile rule of the triangular / lower-only GEMMs of the fit (trailing updates, block-row products) with the one-launch factorisation
-for V in 4096 512 128 64; do
-echo "128-tiles from $V tri tiles: $(GPLE_GEMM_128_MIN_TILES_TRI=$V timeout -k 10 150 python probes/fit_timing.py real 4096 8192 2>&1 | grep 'fit ' | awk '{printf "%s ", $4}')"
-done
-for V in 256 512 1024; do
-echo "split-k up to $V tiles: $(GPLE_GEMM_SPLITK_MAX_TILES=$V timeout -k 10 150 python probes/fit_timing.py real 4096 8192 2>&1 | grep 'fit ' | awk '{printf "%s ", $4}')"
-done
+# first cut of the n = 4096 factorisation: forks x tile budget (the trailing update after the first block has (n - J)^2 J flops on (n - J)^2 / 8192 tiles)
+for F in "60,80" "64,82" "67,84" "70,85" "56,78"; do for B in 1600 2400 3200; do
+echo "forks $F budget $B: $(GPLE_CHOL_FORKS=$F GPLE_CHOL_TILE_BUDGET=$B timeout -k 10 150 python probes/fit_timing.py real 4096 2>&1 | grep 'fit ' | awk '{printf "%s %s %s", $4, $5, $6}')"
+done; done
