@@ -251,3 +251,14 @@ def test_flag_epochs_start_over():
     stream order) long before it could run out — here after every third fit (GPLE_CHOL_DAG_EPOCH_LIMIT=3): twelve fits of changing sizes, each
     with the fit's identities"""
     _fit_in_own_process({"GPLE_CHOL_DAG_EPOCH_LIMIT": "3"}, (1024, 4096, 512, 2304, 4096, 1024, 256, 4096, 3072, 1024, 2560, 512))
+
+
+def test_inverse_in_the_launch_against_the_merge_trees():
+    """T = L^-1 below the diagonal blocks comes from tile tasks of the panel launch (one-block matrices: all of it; larger ones: the diagonal part of every row
+    block behind the first fork) or from merge trees of GEMMs (GPLE_CHOL_DAG_INVERSE=0, GPLE_CHOL_DAG_BLOCK_INVERSE=0): two summation orders, the same v"""
+    sizes = (256, 1024, 3072, 4096, 6144)
+    a = _fit_in_own_process({}, sizes)
+    b = _fit_in_own_process({"GPLE_CHOL_DAG_INVERSE": "0", "GPLE_CHOL_DAG_BLOCK_INVERSE": "0"}, sizes)
+    for N in sizes:
+        assert np.abs(a["v%d" % N] - b["v%d" % N]).max() <= 1e-7 * np.abs(b["v%d" % N]).max(), N
+        assert abs(a["e%d" % N] - b["e%d" % N]) <= 1e-7 * b["e%d" % N], N
