@@ -176,9 +176,14 @@ namespace gple
 		// goes to rinv) and positivity is checked on the reciprocals after the sweep.  Software-pipelined by hand: iteration k
 		// runs the 1/sqrt chain of column k while the rank-1 update of column k - 1 is applied to the columns right of k; only
 		// the update of column k + 1 by column k sits between two pivots.
-		template <int SP>
-		__device__ __forceinline__ void diag_chain(double* S, double* rinv, int lane, int& first_bad)
+		// INV_LAST (last sub-panel only): the sweep also yields the INVERSE of the last 16 x 16 diagonal tile.  Rows below a diagonal tile leave a sweep
+		// as A21 L^-T; with the identity in their place (lanes 16-31 — the last sub-panel has no rows below of its own) that is L^-T, whose row i is
+		// column i of T = L^-1: written to tile (3, 3) of TIout (row-major, zeros above the diagonal), 0.1 us more for the sweep instead of a
+		// substitution of 16 dependent steps (diag_inv16, 1.2 us) after it.
+		template <int SP, bool INV_LAST = false>
+		__device__ __forceinline__ void diag_chain(double* S, double* rinv, int lane, int& first_bad, double* TIout = nullptr)
 		{
+			static_assert(!INV_LAST || SP == 3, "only the last sub-panel has free lanes below its tile");
 			constexpr int base = 16 * SP;
 			const int own = min(base + lane, NB - 1);
 			double p[16], q[16], rr[16];
@@ -186,9 +191,13 @@ namespace gple
 			const double* const qrow = S + (base + (lane & 15)) * DLS + base;
 #pragma unroll
 			for (int k = 0; k < 16; ++k) p[k] = prow[k], q[k] = qrow[k];
+			if constexpr (INV_LAST)
+				if (lane >= 16)
+#pragma unroll
+					for (int k = 0; k < 16; ++k) p[k] = k == (lane & 15) ? 1.0 : 0.0;
 			// the broadcast carries -L(base + j, k); the per-lane factor is the lane's own multiplier (l for p, lq for q)
 			double nlq = 0.0, lq = 0.0, l = 0.0;
-			constexpr bool ROWS_BELOW = SP < 3; // the last sub-panel is its diagonal tile only: p == q in the one DPP row that counts
+			constexpr bool ROWS_BELOW = SP < 3 || INV_LAST; // the last sub-panel is its diagonal tile only: p == q in the one DPP row that counts
 			[&]<int... Ks>(std::integer_sequence<int, Ks...>)
 			{
 				(
@@ -225,6 +234,10 @@ namespace gple
 			if (base + lane < NB)
 #pragma unroll
 				for (int k = 0; k < 16; ++k) prow[k] = p[k];
+			if constexpr (INV_LAST)
+				if (lane >= 16 && lane < 32)
+#pragma unroll
+					for (int k = 0; k < 16; ++k) TIout[(base + k) * DLS + base + (lane & 15)] = p[k]; // T(k, i) = (L^-T)(i, k); zero for k < i
 			int fb = 0;
 #pragma unroll
 			for (int k = 15; k >= 0; --k) fb = (rr[k] > 0.0 && rr[k] < __builtin_inf()) ? fb : base + k + 1;
@@ -1506,7 +1519,7 @@ namespace gple
 				stamp(9);
 				if (w == 1) poll();
 				if (w > 1) look();
-				if (w == 0) diag_chain<3>(S, rinv, lane, first_bad);
+				if (w == 0) diag_chain<3, true>(S, rinv, lane, first_bad, TI); // ... and the inverse of the last diagonal tile with it
 				else if (w == 1) diag_inv16(S, rinv, TI, 2, lane);
 				else if (w == 2) v_acc(2, 0, 1, false), store_tt_cols(k, 16, 16);
 				else
@@ -1519,10 +1532,11 @@ namespace gple
 				stamp(10);
 				if (w == 1) poll();
 				look();
-				if (w == 0) diag_inv16(S, rinv, TI, 3, lane);
-				else if (w == 1) t_fin(2, 0), v_acc(3, 0, 2, false); // LDS operations of one wave complete in order
-				else if (w == 2) t_fin(2, 1), v_acc(3, 1, 2, false);
-				else v_acc(3, 2, 2, true), watch();
+				// (waves 0 and 1 ask for the coming panel's fragments in this stage — 16 loads of four 128-byte segments, 0.4 us —, waves 2 and 3 did in the
+				// stage before: the two longer products go to those)
+				if (w == 0) v_acc(3, 2, 2, true);
+				else if (w == 2) t_fin(2, 0), v_acc(3, 0, 2, false); // LDS operations of one wave complete in order
+				else if (w == 3) t_fin(2, 1), v_acc(3, 1, 2, false), watch();
 				lds_barrier();
 				stamp(11);
 				look();
