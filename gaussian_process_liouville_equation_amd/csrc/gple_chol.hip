@@ -176,14 +176,15 @@ namespace gple
 		// goes to rinv) and positivity is checked on the reciprocals after the sweep.  Software-pipelined by hand: iteration k
 		// runs the 1/sqrt chain of column k while the rank-1 update of column k - 1 is applied to the columns right of k; only
 		// the update of column k + 1 by column k sits between two pivots.
-		// INV_LAST (last sub-panel only): the sweep also yields the INVERSE of the last 16 x 16 diagonal tile.  Rows below a diagonal tile leave a sweep
-		// as A21 L^-T; with the identity in their place (lanes 16-31 — the last sub-panel has no rows below of its own) that is L^-T, whose row i is
-		// column i of T = L^-1: written to tile (3, 3) of TIout (row-major, zeros above the diagonal), 0.1 us more for the sweep instead of a
-		// substitution of 16 dependent steps (diag_inv16, 1.2 us) after it.
+		// INV_LAST (sub-panels 1-3, which leave lanes without a row): the sweep also yields the INVERSE of its 16 x 16 diagonal tile.  Rows below a
+		// diagonal tile leave a sweep as A21 L^-T; with the identity in the free lanes that is L^-T, whose row i is column i of T = L^-1: written to
+		// tile (SP, SP) of TIout (row-major, zeros above the diagonal) — instead of a substitution of 16 dependent steps (diag_inv16, 1.2 us) after the
+		// sweep, which for the last sub-panel sat on the panel's critical path.
 		template <int SP, bool INV_LAST = false>
 		__device__ __forceinline__ void diag_chain(double* S, double* rinv, int lane, int& first_bad, double* TIout = nullptr)
 		{
-			static_assert(!INV_LAST || SP == 3, "only the last sub-panel has free lanes below its tile");
+			static_assert(!INV_LAST || SP >= 1, "the first sub-panel has no free lanes below its rows");
+			constexpr int FREE0 = NB - 16 * SP; // first lane without a row of its own (sub-panel SP has 64 - 16 SP rows from its diagonal tile down)
 			constexpr int base = 16 * SP;
 			const int own = min(base + lane, NB - 1);
 			double p[16], q[16], rr[16];
@@ -192,7 +193,7 @@ namespace gple
 #pragma unroll
 			for (int k = 0; k < 16; ++k) p[k] = prow[k], q[k] = qrow[k];
 			if constexpr (INV_LAST)
-				if (lane >= 16)
+				if (lane >= FREE0)
 #pragma unroll
 					for (int k = 0; k < 16; ++k) p[k] = k == (lane & 15) ? 1.0 : 0.0;
 			// the broadcast carries -L(base + j, k); the per-lane factor is the lane's own multiplier (l for p, lq for q)
@@ -235,7 +236,7 @@ namespace gple
 #pragma unroll
 				for (int k = 0; k < 16; ++k) prow[k] = p[k];
 			if constexpr (INV_LAST)
-				if (lane >= 16 && lane < 32)
+				if (lane >= FREE0 && lane < FREE0 + 16)
 #pragma unroll
 					for (int k = 0; k < 16; ++k) TIout[(base + k) * DLS + base + (lane & 15)] = p[k]; // T(k, i) = (L^-T)(i, k); zero for k < i
 			int fb = 0;
@@ -1458,7 +1459,7 @@ namespace gple
 				else upd(2, 2, 0);
 				lds_barrier();
 				stamp(5);
-				if (w == 0) diag_chain<1>(S, rinv, lane, first_bad);
+				if (w == 0) diag_chain<1, true>(S, rinv, lane, first_bad, TI); // (with the inverse of its diagonal tile: the 16 lanes below its 48 rows)
 				else if (w == 1) diag_inv16(S, rinv, TI, 0, lane);
 				else if (w == 2) upd(3, 2, 0);
 				else
@@ -1503,48 +1504,42 @@ namespace gple
 						request_inputs(k + 1), have = true;
 					}
 				};
+				// With every diagonal tile's inverse coming out of its own sweep (the first one's from wave 1 beside the second sweep), the block rows of T_k
+				// are a stage ahead of where a substitution per tile put them: row 3 is complete but for its last factor when the last sweep ends.
 				if (w == 1) poll();
-				if (w == 0) diag_chain<2>(S, rinv, lane, first_bad);
-				else if (w == 1) diag_inv16(S, rinv, TI, 1, lane);
+				if (w == 0) diag_chain<2, true>(S, rinv, lane, first_bad, TI);
+				else if (w == 1) t_fin(1, 0);
 				else if (w == 2) v_acc(2, 0, 0, true);
 				else v_acc(3, 0, 0, true), store_tt_cols(k, 0, 16);
 				lds_barrier();
 				stamp(8);
 				if (w == 1) poll();
+				if (w == 0) look();
 				if (w == 0) upd(3, 3, 2);
-				else if (w == 1) t_fin(1, 0);
+				else if (w == 1) v_acc(2, 0, 1, false);
 				else if (w == 2) v_acc(2, 1, 1, true);
-				else v_acc(3, 1, 1, true);
+				else v_acc(3, 0, 1, false), v_acc(3, 1, 1, true);
 				lds_barrier();
 				stamp(9);
 				if (w == 1) poll();
-				if (w > 1) look();
-				if (w == 0) diag_chain<3, true>(S, rinv, lane, first_bad, TI); // ... and the inverse of the last diagonal tile with it
-				else if (w == 1) diag_inv16(S, rinv, TI, 2, lane);
-				else if (w == 2) v_acc(2, 0, 1, false), store_tt_cols(k, 16, 16);
+				if (w > 0) look();
+				if (w == 0) diag_chain<3, true>(S, rinv, lane, first_bad, TI);
+				else if (w == 1) t_fin(2, 0), v_acc(3, 0, 2, false); // LDS operations of one wave complete in order
+				else if (w == 2) t_fin(2, 1), v_acc(3, 1, 2, false), store_tt_cols(k, 16, 16);
 				else
 				{
-					v_acc(3, 0, 1, false);
-					store_t_rows(k, 0, 0, 4), store_t_rows(k, 1, 0, 4); // complete since the barrier above
+					v_acc(3, 2, 2, true);
+					store_t_rows(k, 0, 0, 4), store_t_rows(k, 1, 0, 4); // complete since the stage before the last
 					watch();
 				}
 				lds_barrier();
 				stamp(10);
-				if (w == 1) poll();
-				look();
-				// (waves 0 and 1 ask for the coming panel's fragments in this stage — 16 loads of four 128-byte segments, 0.4 us —, waves 2 and 3 did in the
-				// stage before: the two longer products go to those)
-				if (w == 0) v_acc(3, 2, 2, true);
-				else if (w == 2) t_fin(2, 0), v_acc(3, 0, 2, false); // LDS operations of one wave complete in order
-				else if (w == 3) t_fin(2, 1), v_acc(3, 1, 2, false), watch();
-				lds_barrier();
-				stamp(11);
 				look();
 				if (w < 3) t_fin_out(k, w);
 				else store_t_rows(k, 2, 0, 4), store_t_rows(k, 3, 48, 1);
 				if (first_bad != 0 && t == 0) atomicCAS(a.info, 0, j0 + first_bad);
 				lds_barrier();
-				stamp(12);
+				stamp(11);
 				if (k + 1 == a.C1)
 				{
 					store_tt_cols(k, 32 + 8 * w, 8);
@@ -1779,7 +1774,7 @@ namespace gple
 				const bool side_busy = marks != nullptr && !marks->empty() && J0 >= marks->front();
 				const int max_blocks = side_busy && late_blocks >= 2 ? std::min(late_blocks, chol_dag_max_blocks()) : chol_dag_max_blocks();
 				const int helpers = std::min(max_blocks - 1, g.nunits);
-				constexpr int LAST_STAMP = 12;
+				constexpr int LAST_STAMP = 11;
 				static const bool want_stamps = getenv("GPLE_CHOL_DAG_STAMPS") != nullptr;
 				static long long* stamp_buf = nullptr;
 				if (want_stamps && stamp_buf == nullptr && hipMalloc(reinterpret_cast<void**>(&stamp_buf), 16 * 1024 * sizeof(long long)) != hipSuccess) stamp_buf = nullptr;
