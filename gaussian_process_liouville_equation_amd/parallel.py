@@ -132,7 +132,7 @@ def allgather_element_scalars(values, n_elements, width, group=None, device="cpu
 DEAL_BLOCK = 128    # SHARD_BLOCK of csrc/gple_capi.hip
 DEAL_CYCLE = 64     # blocks per cycle of a hybrid plan's weights (8192 grid points: fine against a 512 x 512 grid's 2048 blocks)
 # measured on MI355X: fit(error + averages) by padded matrix size n, contraction rate of rownorm2_kernel, K* generation bandwidth
-FIT_MS_BY_N = {256: 0.100, 1024: 0.30, 2048: 0.575, 4096: 1.62, 8192: 8.4, 16384: 58.0}
+FIT_MS_BY_N = {256: 0.093, 1024: 0.274, 2048: 0.536, 4096: 1.6, 8192: 8.35, 16384: 58.0}
 CONTRACT_FLOPS = 69.3e12
 KSTAR_GEN_BYTES_PER_S = 5.4e12
 GATHER_MS = 0.08    # one all-gather of <= 25 MB in 8 shares: latency-bound
