@@ -1139,7 +1139,7 @@ namespace gple
 						for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ch & 1][b][q], y[ch & 1][q], acc[b], 0, 0, 0);
 				}
 			}
-			if (!dag_wait(a, dag_t(a, r), nullptr, nullptr, lane, true)) return false;
+			if (!dag_wait(a, dag_t(a, r), nullptr, nullptr, lane, r + 1 < a.C1)) return false; // (the last row's tiles are what the launch ends with: they look often)
 			const double* const Tt = a.T + static_cast<long>(r) * NB * (a.ldt + 1) + fr;
 			double xt[40];
 			[&]<int... Bs>(std::integer_sequence<int, Bs...>)
