@@ -6,8 +6,10 @@ One step = what the reference does per output tick for one density-matrix elemen
 + PredictiveKernel(grid, kernel, false): mean, variance, cut-off    (output.cpp:204-207)
 Default workload C4r = the north-star size of BASELINE.json (N = 4096 samples, 512 x 512 grid, real SE kernel, fp64),
 synthetic inputs of SURVEY.md §8(d) (seed 20240607 + 1).  Inputs are resident in HBM before the timed region.
-N > 1 GPUs: strong scaling of the same step — every rank fits (replicated, no broadcast needed) and predicts its
-contiguous slice of the grid (parallel.GridShardedStep); the slices are all-gathered over RCCL (the north-star partition).
+N > 1 GPUs: strong scaling of the same step — every rank fits (replicated, no broadcast needed) and predicts its share of a
+block-cyclic deal of the grid (128-point blocks, block b -> rank b mod P: gple_*_predict_sharded); the shares are all-gathered over RCCL
+inside the library (the north-star partition).  `python bench.py --gpus N` starts its N ranks itself (launch_ranks) when it is not already
+running under torch.distributed.run.
 `--workload C4opt` is the optimiser's inner loop instead (opt.cpp:441-482): one step = loose_function value + gradient of
 the three density-matrix elements of a 2-state system (2 real + 1 complex GP, N = 4096, 5N extra points each).
 """
@@ -154,12 +156,11 @@ class _NcclUniqueId(C.Structure):
 _RCCL = {}
 
 
-def make_rccl_comm(torch, dist, rank, world):
-    """An ncclComm_t over all ranks for the library's own collective (gple_*_predict_sharded / _dealt): rank 0 draws the unique id, the 128
-    bytes travel over torch.distributed's control group, every rank joins with ncclCommInitRank on its current device.  librccl is loaded
-    RTLD_GLOBAL — torch's own copy when it ships one, so that the process holds ONE RCCL — and libgple_hip.so finds ncclAllGather in the
-    process image, i.e. in the library this communicator belongs to."""
-    if os.environ.get("BENCH_FORCE_COMM_FAIL"):  # rehearsal of the fallback
+def _rccl_load(torch, rank):
+    """phase 1 of the communicator setup, local to a rank: librccl loaded RTLD_GLOBAL — torch's own copy when it ships one, so that the
+    process holds ONE RCCL and libgple_hip.so finds ncclAllGather in the process image, i.e. in the library the communicator belongs to —
+    and, on rank 0, the unique id"""
+    if os.environ.get("BENCH_FORCE_COMM_FAIL") in ("1", f"rank{rank}"):  # rehearsal of the fallback: on every rank, or on ONE rank only
         raise RuntimeError("BENCH_FORCE_COMM_FAIL is set")
     cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"]
     path = next((q for q in cands if os.path.exists(q)), "librccl.so.1")
@@ -170,40 +171,56 @@ def make_rccl_comm(torch, dist, rank, world):
         rc = rccl.ncclGetUniqueId(C.byref(uid))
         if rc != 0:
             raise RuntimeError(f"ncclGetUniqueId: {rccl.ncclGetErrorString(rc).decode()}")
+    return rccl, path, uid
+
+
+def _all_ok(torch, dist, world, ok):
+    """every rank enters this with its own verdict and leaves with the common one (MIN over the control group)"""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
     if world > 1:
-        buf = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
         if dist.get_backend() == "nccl":
-            buf = buf.cuda()
-        dist.broadcast(buf, 0)
-        C.memmove(C.byref(uid), bytes(buf.cpu().numpy().tobytes()), 128)
-    comm = C.c_void_p()
-    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
-    rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
-    if rc != 0:
-        raise RuntimeError(f"ncclCommInitRank(rank {rank} of {world}): {rccl.ncclGetErrorString(rc).decode()}")
-    _RCCL["lib"] = rccl
-    return comm, path
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
 
 
 def try_rccl_comm(torch, dist, rank, world):
-    """make_rccl_comm, or (None, path, reason) on EVERY rank when it failed on any (the ranks agree over the control group): the caller then
-    falls back to torch.distributed's own RCCL group and says so in the JSON line — a scaling run that dies in communicator setup measures nothing."""
-    comm, path, why = None, None, ""
+    """An ncclComm_t over all ranks for the library's own collective (gple_*_predict_sharded / _dealt), or (None, path, reason) on EVERY rank
+    when any rank failed: the caller then falls back to torch.distributed's own RCCL group and says so in the JSON line — a scaling run that dies
+    in communicator setup measures nothing.  Two phases, each closed by an agreement over the control group, so that the collectives on that
+    group stay matched whichever rank fails where: (1) load librccl + rank 0 draws the unique id — local, under try; agree; (2) only if all ranks
+    are ok: the 128 bytes travel by broadcast, every rank joins with ncclCommInitRank on its current device — under try; agree."""
+    rccl, path, uid, why = None, None, None, ""
     try:
-        comm, path = make_rccl_comm(torch, dist, rank, world)
-    except Exception as e:  # noqa: BLE001 - anything: missing library, symbol, ncclCommInitRank error
+        rccl, path, uid = _rccl_load(torch, rank)
+    except Exception as e:  # noqa: BLE001 - anything: missing library, symbol, ncclGetUniqueId error
         why = f"rank {rank}: {type(e).__name__}: {e}"
-    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
-    if world > 1:
-        if dist.get_backend() == "nccl":
-            ok = ok.cuda()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0:
+    comm = None
+    if _all_ok(torch, dist, world, rccl is not None):
+        if world > 1:  # every rank is here: the broadcast is matched
+            buf = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+            if dist.get_backend() == "nccl":
+                buf = buf.cuda()
+            dist.broadcast(buf, 0)
+            C.memmove(C.byref(uid), bytes(buf.cpu().numpy().tobytes()), 128)
+        try:
+            if os.environ.get("BENCH_FORCE_COMM_FAIL") == f"init{rank}":
+                raise RuntimeError("BENCH_FORCE_COMM_FAIL is set (ncclCommInitRank)")
+            comm = C.c_void_p()
+            rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+            rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+            if rc != 0:
+                comm = None
+                raise RuntimeError(f"ncclCommInitRank(rank {rank} of {world}): {rccl.ncclGetErrorString(rc).decode()}")
+            _RCCL["lib"] = rccl
+        except Exception as e:  # noqa: BLE001
+            comm, why = None, f"rank {rank}: {type(e).__name__}: {e}"
+        if _all_ok(torch, dist, world, comm is not None):
+            return comm, path, ""
         if comm is not None:
             destroy_rccl_comm(comm)
-        sys.stderr.write(f"bench.py: the library-side RCCL communicator could not be created ({why or 'on another rank'}); falling back to torch.distributed\n")
-        return None, path, why or "failed on another rank"
-    return comm, path, ""
+    sys.stderr.write(f"bench.py: the library-side RCCL communicator could not be created ({why or 'on another rank'}); falling back to torch.distributed\n")
+    return None, path, why or "failed on another rank"
 
 
 def destroy_rccl_comm(comm):
@@ -211,6 +228,52 @@ def destroy_rccl_comm(comm):
     if rccl is not None and comm:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def launch_ranks(nproc, script_argv, out=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as child processes of THIS process — which has not touched
+    the GPU (the call sits in front of `import torch`; nothing is exec'ed over a process that holds a GPU context) — through
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py ...`, i.e. the
+    driver's own command line.  The children's stdout is collected: rank 0 prints the result line (the other ranks' stdout is pointed at
+    stderr by _keep_stdout_for_the_json_line), anything else that reached stdout (a banner of a library) goes to stderr here, and exactly ONE
+    JSON line leaves on stdout.  Returns the exit code: the launcher's if it failed (a rank that dies takes the others down through
+    torch.distributed.run), 1 if no result line came, else 0."""
+    import socket
+    out = out or sys.stdout
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", str(port)] + list(script_argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    try:
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        sys.stderr.write(f"bench.py: the {nproc} ranks did not finish within {timeout} s\n")
+        sys.stderr.write((e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""))
+        return 124
+    line = None
+    for ln in proc.stdout.splitlines():
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                if "metric" in json.loads(t):
+                    line = t
+                    continue
+            except ValueError:
+                pass
+        if t:
+            sys.stderr.write(ln + "\n")
+    if proc.returncode != 0:
+        sys.stderr.write(f"bench.py: torch.distributed.run exited with {proc.returncode}\n")
+        return proc.returncode
+    if line is None:
+        sys.stderr.write("bench.py: no result line from rank 0\n")
+        return 1
+    out.write(line + "\n")
+    out.flush()
+    return 0
 
 
 def _keep_stdout_for_the_json_line():
@@ -257,6 +320,10 @@ def main():
                          "ranks and all-gathered; 'elements' = weak scaling over the independent density-matrix elements, every "
                          "rank fits and predicts its own element on the whole grid, no data-path collective (SURVEY.md §8e)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process has made no GPU call yet (torch is not even imported), so it may start the N
+        # ranks as fresh children and relay rank 0's line
+        sys.exit(launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     OUT = _keep_stdout_for_the_json_line()
 
     import torch
@@ -327,8 +394,8 @@ def main():
     # --via capi: the product's own collective.  One ncclComm_t per process from the librccl of this process; the library resolves
     # ncclAllGather from the process image, i.e. from the same library.
     capi = args.via == "capi" and not by_element and (world > 1 or args.comm_at_one) and not os.environ.get("BENCH_COMM_UNUSED")
-    if os.environ.get("BENCH_COMM_UNUSED"):
-        make_rccl_comm(torch, dist, rank, world)
+    if os.environ.get("BENCH_COMM_UNUSED"):  # a communicator in the process that the step does not use (A/B of the hardware-queue hazard)
+        _RCCL["unused"] = try_rccl_comm(torch, dist, rank, world)[0]
     comm, via_note = None, ("torch.distributed all_gather_into_tensor" if world > 1 else "no collective (one rank)")
     if capi:
         comm, rccl_path, why = try_rccl_comm(torch, dist, rank, world)
@@ -792,7 +859,7 @@ def opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev):
             for i, v in vals.items():
                 buf[i] = torch.as_tensor(v, dtype=torch.float64)
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-            return torch.nan_to_num(buf, nan=1.7976931348623157e308, posinf=1.7976931348623157e308, neginf=1.7976931348623157e308)
+            return buf  # raw sums: the sanity check below must see a NaN of any rank's part; make_normal (opt.cpp:420-431) belongs to the value handed to an optimiser
         allv = parallel.allgather_element_scalars(vals, 3, 9, device="cuda" if (world > 1 and args.control == "nccl") else "cpu")
         return allv
 
