@@ -11,6 +11,7 @@ import weakref
 import numpy as np
 
 GPLE_OK = 0
+GPLE_ERR_TIMEOUT = 6  # a draining call noticed that the one-launch factorisation had given up: the fit is recovered, work enqueued before it is NaN (include/gple.h)
 CALC_ERROR = 0x1
 CALC_AVERAGE = 0x2
 CALC_DERIVATIVE = 0x4

@@ -168,6 +168,7 @@ namespace
 	constexpr int SDEV_N = 512;        // [0] s, [1..15] base sums, [16..28] real derivative sums, [31] info, [32..39] complex error derivative,
 	                                   // [64..108] complex purity quadratic forms (5 kernels x 9), [128..287] aux dots (5 x 8 x 4)
 	constexpr int HS_PRED_ERR = 512, HS_PRED_DERIV = 520, HS_NLML = 540;
+	constexpr int SDEV_INFO = 31; // the factorisation's info word (an int in the double's slot; the finish kernels read it: gple_kernels.hip, fit_gave_up)
 	// a handful of test points with host pointers (the reference's one-point predicts): inputs and outputs go through the pinned
 	// block itself (device-visible), not through four hipMemcpyAsync of pageable memory
 	constexpr int HS_FEW_XS = 600, HS_FEW_LAB = 640, HS_FEW_MEAN = 680, HS_FEW_VAR = 720, HS_FEW_CUT = 740;
@@ -235,6 +236,12 @@ struct FitCommon
 	double* sdev = nullptr; // [0] rescale factor, [1..] raw sums, [31] info (as int)
 	double s_host = 0.0;
 	bool sc_ready = false; // host scalars computed (deferred when the caller passed no scalars struct)
+	// The one-launch factorisation may give up waiting (info = -1, gple_chol.hip): the device then turns everything derived from T into NaN, and
+	// the first host synchronisation on this fit (validate_fit: the scalar getters, every *_fit_get, a predict that drains the stream) repeats
+	// the factorisation with a launch per panel.  Calls that consumed the fit before that — enqueued, never synchronised — have produced NaN:
+	mutable std::atomic<bool> validated{false}; // the host has seen info >= 0 (or has recovered)
+	mutable std::atomic<int> stale_uses{0};     // predicts enqueued on the not yet validated fit
+	unsigned deriv_mask = 0xFFu; // which parameters' N^3 products a derivative fit forms (bit ip; gple_objective_eval_part splits them over ranks)
 	SEParamSet ps{};
 	double self = 0.0; // k(x*, x*)
 	FitCommon() { std::memset(dspec, 0, sizeof(dspec)); }
@@ -292,6 +299,7 @@ namespace
 		return GPLE_OK;
 	}
 
+	int fit_factor(gple_ctx* ctx, FitCommon* f);
 	// shared front half of both fits: upload, label scaling, Gram, Cholesky, inverse factor, weights
 	int fit_common(gple_ctx* ctx, FitCommon* f, const double* X, const double* y, int y_stride, size_t N, unsigned flags)
 	{
@@ -322,13 +330,10 @@ namespace
 			f->wx = ctx->acquire(static_cast<size_t>(Np) * 8, &e);
 			GPLE_HIP(ctx, e);
 		}
-		Scratch ytmp(ctx), Lbuf(ctx), work(ctx), part(ctx), u(ctx);
+		Scratch ytmp(ctx);
 		timer_start(ctx, GPLE_TIMER_FIT);
 		const size_t ylen = N * static_cast<size_t>(y_stride);
 		GPLE_HIP(ctx, ytmp.get(ylen));
-		GPLE_HIP(ctx, Lbuf.get(static_cast<size_t>(nt + CHOL_NB) * nt));
-		GPLE_HIP(ctx, work.get(chol_inverse_work_doubles(nt)));
-		GPLE_HIP(ctx, u.get(nt));
 
 		// device inputs are read in place; host inputs are staged by two copies.  One launch then pads the points, clears the
 		// scalar block and rescales the labels (every launch costs 2.9 us on the GPU timeline)
@@ -342,6 +347,20 @@ namespace
 			Xin = xtmp.p, yin = ytmp.p;
 		}
 		GPLE_HIP(ctx, launch_prep_labels(st, yin, y_stride, f->is_complex ? 1 : 0, f->N, Np, f->ys, f->sdev, Xin, f->Xt, SDEV_N));
+		return fit_factor(ctx, f);
+	}
+
+	// Gram, Cholesky, inverse factor, weights of a fit whose points and scaled labels are in place (fit_common; recover_fit repeats it under the
+	// launch-per-panel scheme after a give-up).  The scheme is the calling thread's (CholSchemeScope) or the context's (debug knob).
+	int fit_factor(gple_ctx* ctx, FitCommon* f)
+	{
+		hipStream_t st = ctx->stream;
+		const int Np = f->Np, nt = f->n_total;
+		CholSchemeScope scheme(ctx->chol_scheme);
+		Scratch Lbuf(ctx), work(ctx), u(ctx);
+		GPLE_HIP(ctx, Lbuf.get(static_cast<size_t>(nt + CHOL_NB) * nt));
+		GPLE_HIP(ctx, work.get(chol_inverse_work_doubles(nt)));
+		GPLE_HIP(ctx, u.get(nt));
 		// T is lower block-triangular and every consumer keeps to the blocks on and below the diagonal (the diagonal 64-blocks leave the
 		// panel step complete, zeros above the diagonal included), so the blocks above are never written and never read: no 8 n^2-byte
 		// memset in front of the factorisation (35 us at n = 4096).  GPLE_POISON_T=1 fills T with NaN bit patterns first — the GPU
@@ -357,7 +376,7 @@ namespace
 		GPLE_HIP(ctx, launch_gram_train(st, f->Xt, f->N, Np, nt, f->ps, Lbuf.p, ldl, f->ys));
 		int* info_dev = reinterpret_cast<int*>(f->sdev + 31);
 		GPLE_HIP(ctx, chol_inverse_factor(ctx, st, Lbuf.p, ldl, nt, f->T, nt, info_dev, work.p, u.p));
-		GPLE_HIP(ctx, launch_colpass(st, f->T, nt, nt, u.p, f->v, f->w, Np, f->wx));
+		GPLE_HIP(ctx, launch_colpass(st, f->T, nt, nt, u.p, f->v, f->w, Np, f->wx, info_dev)); // (a give-up of the factorisation: NaN)
 		return GPLE_OK;
 	}
 
@@ -388,7 +407,7 @@ namespace
 			const double* Dd = D.p + d * n2;
 			GPLE_HIP(ctx, launch_gemv(st, Dd, nt, nt, f->v, 1.0, part.p, tvec.p));
 			GPLE_HIP(ctx, launch_gemv(st, f->W, nt, nt, tvec.p, -1.0, part.p, dv + static_cast<size_t>(1 + d) * nt));
-			if (!(ctx->deriv_mask >> (1 + d) & 1u)) // another rank forms this parameter's diag(W dK W) (gple_objective_eval_part); (dW) y above is needed by every rank's predict
+			if (!(f->deriv_mask >> (1 + d) & 1u)) // another rank forms this parameter's diag(W dK W) (gple_objective_eval_part); (dW) y above is needed by every rank's predict
 			{
 				GPLE_HIP(ctx, hipMemsetAsync(dwd.p + static_cast<size_t>(1 + d) * nt, 0, static_cast<size_t>(nt) * sizeof(double), st));
 				continue;
@@ -502,7 +521,7 @@ namespace
 			GPLE_HIP(ctx, launch_typed_deriv_gram(st, f->Xt, f->N, Np, nt, f->dspec[ip - 1], D.p));
 			GPLE_HIP(ctx, launch_gemv(st, D.p, nt, nt, f->v, 1.0, part.p, tvec.p));
 			GPLE_HIP(ctx, launch_gemv(st, f->W, nt, nt, tvec.p, -1.0, part.p, dw + static_cast<size_t>(ip) * nt));
-			if (!(ctx->deriv_mask >> ip & 1u)) // another rank forms this parameter's diagonals (gple_objective_eval_part)
+			if (!(f->deriv_mask >> ip & 1u)) // another rank forms this parameter's diagonals (gple_objective_eval_part)
 			{
 				GPLE_HIP(ctx, hipMemsetAsync(dwd.p + static_cast<size_t>(ip) * nt, 0, static_cast<size_t>(nt) * sizeof(double), st));
 				GPLE_HIP(ctx, hipMemsetAsync(dwx.p + static_cast<size_t>(ip) * Np, 0, static_cast<size_t>(Np) * sizeof(double), st));
@@ -698,6 +717,7 @@ extern "C"
 		{
 		case GPLE_OK: return "ok";
 		case GPLE_ERR_BAD_ARG: return "bad argument";
+		case GPLE_ERR_TIMEOUT: return "the factorisation gave up waiting; results enqueued before the synchronisation that noticed are NaN";
 		case GPLE_ERR_HIP: return "HIP runtime error";
 		case GPLE_ERR_ALLOC: return "device allocation failed";
 		case GPLE_ERR_STATE: return "requested output was not computed by this fit (flags), or the context was destroyed";
@@ -922,11 +942,97 @@ extern "C"
 	// Host side of TrainingKernel's scalar members: drains the stream, reads the raw device sums back and applies the
 	// closed-form factors.  Called with ctx->call_mu held, either from gple_real_fit_create (scalars requested) or later
 	// from gple_real_fit_get_scalars.
+	// what follows the factorisation of a real fit: the raw sums of the scalar members (+ the derivative members); enqueue only
+	static int real_fit_post(gple_ctx* ctx, gple_real_fit* f)
+	{
+		hipStream_t st = ctx->stream;
+		const unsigned flags = f->flags;
+		const double sf = f->theta[0], l0 = f->theta[1], l1 = f->theta[2], sn = f->theta[3];
+		const size_t N = f->N;
+		Scratch part(ctx);
+		const size_t g = (N + 63) / 64;
+		const bool avg = (flags & GPLE_CALC_AVERAGE) != 0;
+		if (avg) // purity: v^T K1 v; its per-block partials are summed by the same launch that forms the other sums
+		{
+			GPLE_HIP(ctx, part.get(g * g));
+			GPLE_HIP(ctx, launch_quadform_partials(st, f->Xt, f->N, purity_aux(sf, l0, l1), f->v, f->v, -1, part.p));
+		}
+		GPLE_HIP(ctx, launch_real_fit_sums(st, f->Xt, f->ys, f->v, f->w, f->N, f->sdev + 1, avg ? part.p : nullptr, static_cast<int>(g * g), f->sdev + 6));
+		if (flags & GPLE_CALC_DERIVATIVE) GPLE_TRY(real_fit_derivatives(ctx, f, sf, l0, l1, sn, flags));
+		return GPLE_OK;
+	}
+	static int complex_fit_post(gple_ctx* ctx, gple_complex_fit* f);
+
+	// A give-up of the one-launch factorisation (info = -1; the stream is drained, call_mu held): the SAME fit again with one launch per panel
+	// — the scheme of rounds 2-3, no workgroup of which waits for another — from the Gram on: points, scaled labels and parameters are the
+	// handle's, the factorisation is in place so the Gram is regenerated (28 us at n = 4096), and the layout is the one a process started
+	// with GPLE_CHOL_SCHEME=step uses, so the recovered fit has that process's bits (tests/test_gpu_chol_diag.py).  Products of the bad
+	// factor that were built lazily (W, the derivative vectors) are dropped and rebuilt.
+	static int recover_fit(gple_ctx* ctx, FitCommon* f)
+	{
+		hipStream_t st = ctx->stream;
+		ctx->dag_recoveries += 1;
+		for (double** p : {&f->W, &f->dv})
+		{
+			ctx->give_back(*p);
+			*p = nullptr;
+		}
+		GPLE_HIP(ctx, hipMemsetAsync(f->sdev + SDEV_INFO, 0, sizeof(double), st));
+		int status;
+		{
+			CholSchemeScope step(0);
+			const int keep = ctx->chol_scheme;
+			ctx->chol_scheme = -1; // (the scope above decides; a context forced to the one-launch scheme by the debug knob recovers like any other)
+			status = fit_factor(ctx, f);
+			ctx->chol_scheme = keep;
+		}
+		if (status == GPLE_OK)
+			status = f->is_complex ? complex_fit_post(ctx, static_cast<gple_complex_fit*>(f)) : real_fit_post(ctx, static_cast<gple_real_fit*>(f));
+		return status;
+	}
+	// reads the fit's scalar block back into the pinned host block (drains the stream), looks at the factorisation's info word and recovers
+	// from a give-up.  GPLE_ERR_TIMEOUT: the repeated factorisation gave up as well (cannot happen — it has no waits)
+	static int validate_fit(gple_ctx* ctx, const FitCommon* fc)
+	{
+		FitCommon* f = const_cast<FitCommon*>(fc);
+		hipStream_t st = ctx->stream;
+		int info_i = 0;
+		for (int attempt = 0;; ++attempt)
+		{
+			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars, f->sdev, SDEV_N * 8, hipMemcpyDeviceToHost, st));
+			GPLE_HIP(ctx, hipStreamSynchronize(st));
+			std::memcpy(&info_i, ctx->host_scalars + SDEV_INFO, sizeof(int));
+			if (info_i >= 0) break;
+			ctx->dag_giveups += 1;
+			if (attempt == 1)
+			{
+				std::lock_guard<std::mutex> lk(ctx->mu);
+				ctx->last_error = "the factorisation gave up waiting (info = -1) and so did its repetition with one launch per panel";
+				return GPLE_ERR_TIMEOUT;
+			}
+			GPLE_TRY(recover_fit(ctx, f));
+		}
+		f->validated.store(true);
+		return GPLE_OK;
+	}
+	// GPLE_ERR_TIMEOUT for the caller of a synchronising entry point when work enqueued on the fit BEFORE it was validated has consumed a factor that
+	// was then found unfinished: the fit itself is good now, those earlier results are NaN
+	static int report_stale_uses(gple_ctx* ctx, const FitCommon* f, bool recovered)
+	{
+		const int stale = f->stale_uses.exchange(0);
+		if (!recovered || stale == 0) return GPLE_OK;
+		std::lock_guard<std::mutex> lk(ctx->mu);
+		ctx->last_error = "the one-launch factorisation gave up waiting; the fit has been repeated with one launch per panel and is valid now, but "
+			+ std::to_string(stale) + " call(s) enqueued on it before this synchronisation produced NaN: repeat them";
+		return GPLE_ERR_TIMEOUT;
+	}
+
 	static int real_fit_finalize(gple_ctx* ctx, gple_real_fit* f)
 	{
 		hipStream_t st = ctx->stream;
-		GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars, f->sdev, SDEV_N * 8, hipMemcpyDeviceToHost, st));
-		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		(void)st;
+		const long recoveries_before = ctx->dag_recoveries;
+		GPLE_TRY(validate_fit(ctx, f)); // the scalar block is in the pinned host block now, of a factorisation that completed
 		timer_collect(ctx);
 		const unsigned flags = f->flags;
 		const size_t N = f->N;
@@ -978,11 +1084,12 @@ extern "C"
 			}
 		}
 		f->sc_ready = true;
-		return GPLE_OK;
+		return report_stale_uses(ctx, f, ctx->dag_recoveries != recoveries_before);
 	}
 
-	int gple_real_fit_create(gple_ctx* ctx, const double theta[4], const double* X, const double* y, int y_is_complex, size_t N,
-		unsigned flags, gple_real_fit_scalars* scalars, gple_real_fit** out)
+	// deriv_mask: which parameters' N^3 products a derivative fit forms (bit ip) — all of them, except for gple_objective_eval_part
+	static int real_fit_create_masked(gple_ctx* ctx, const double theta[4], const double* X, const double* y, int y_is_complex, size_t N,
+		unsigned flags, unsigned deriv_mask, gple_real_fit_scalars* scalars, gple_real_fit** out)
 	{
 		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 20)) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
@@ -993,31 +1100,17 @@ extern "C"
 		if (!f) return GPLE_ERR_ALLOC;
 		std::memcpy(f->theta, theta, sizeof(f->theta));
 		const double sf = theta[0], l0 = theta[1], l1 = theta[2], sn = theta[3];
-		f->ps.p[0] = f->ps.p[1] = f->ps.p[2] = make_se(sf * sf, sn * sn, l0, l1);
+		(void)l0, (void)l1;
+		f->ps.p[0] = f->ps.p[1] = f->ps.p[2] = make_se(sf * sf, sn * sn, theta[1], theta[2]);
 		f->self = (sf * sf) * (1.0 + (sn * sn) * 1.0); // KernelBase(params, col, col).get_kernel().value(), kernel.cpp:512
 		f->sf = sf;
 		hipStream_t st = ctx->stream;
+		f->deriv_mask = deriv_mask;
 		int status = fit_common(ctx, f, X, y, y_is_complex ? 2 : 1, N, flags);
 		if (status == GPLE_OK)
 		{
-			hipError_t e = hipSuccess;
-			Scratch part(ctx);
-			const size_t g = (N + 63) / 64;
-			const bool avg = (flags & GPLE_CALC_AVERAGE) != 0;
-			if (avg) // purity: v^T K1 v; its per-block partials are summed by the same launch that forms the other sums
-			{
-				e = part.get(g * g);
-				if (e == hipSuccess) e = launch_quadform_partials(st, f->Xt, f->N, purity_aux(sf, l0, l1), f->v, f->v, -1, part.p);
-			}
-			if (e == hipSuccess)
-				e = launch_real_fit_sums(st, f->Xt, f->ys, f->v, f->w, f->N, f->sdev + 1, avg ? part.p : nullptr, static_cast<int>(g * g), f->sdev + 6);
-			if (e == hipSuccess && (flags & GPLE_CALC_DERIVATIVE))
-			{
-				status = real_fit_derivatives(ctx, f, sf, l0, l1, sn, flags);
-				if (status != GPLE_OK) e = hipErrorUnknown;
-			}
+			status = real_fit_post(ctx, f);
 			timer_stop(ctx, GPLE_TIMER_FIT);
-			if (e != hipSuccess && status == GPLE_OK) status = record_hip_error(ctx, e, "real fit reductions", __LINE__);
 		}
 		if (status != GPLE_OK)
 		{
@@ -1027,7 +1120,7 @@ extern "C"
 		}
 		if (scalars) // no struct to fill: everything stays enqueued, gple_real_fit_get_scalars() drains the stream later
 		{
-			status = real_fit_finalize(ctx, f);
+			status = real_fit_finalize(ctx, f); // (nothing was enqueued on the fit before this: never GPLE_ERR_TIMEOUT for stale uses)
 			if (status != GPLE_OK)
 			{
 				delete f;
@@ -1037,6 +1130,11 @@ extern "C"
 		}
 		*out = f;
 		return GPLE_OK;
+	}
+	int gple_real_fit_create(gple_ctx* ctx, const double theta[4], const double* X, const double* y, int y_is_complex, size_t N,
+		unsigned flags, gple_real_fit_scalars* scalars, gple_real_fit** out)
+	{
+		return real_fit_create_masked(ctx, theta, X, y, y_is_complex, N, flags, 0xFFu, scalars, out);
 	}
 	int gple_real_fit_get_scalars(gple_real_fit* fit, gple_real_fit_scalars* out)
 	{
@@ -1077,6 +1175,7 @@ extern "C"
 		const bool dev = flags & GPLE_IO_DEVICE;
 		const size_t N = f->N;
 		const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+		if (!f->validated.load()) GPLE_TRY(validate_fit(ctx, f)); // (a getter drains the stream anyway)
 		switch (which)
 		{
 		case GPLE_R_KERNEL:
@@ -1124,6 +1223,8 @@ extern "C"
 		}();
 		return on;
 	}
+	static int predict_pass(gple_ctx* ctx, const FitCommon* f, const double* Xs, size_t M, unsigned flags, const double* labels,
+		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars, bool* repeat);
 	static int predict_common(gple_ctx* ctx, const FitCommon* f, const double* Xs, size_t M, unsigned flags, const double* labels,
 		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars)
 	{
@@ -1133,10 +1234,22 @@ extern "C"
 			for (double& d : scalars->error_derivative) d = nan_();
 		}
 		if (M == 0) return GPLE_OK;
-		const bool want_deriv = (flags & GPLE_CALC_DERIVATIVE) && labels;
-		if (want_deriv && !f->dv) return GPLE_ERR_STATE; // needs a fit built with GPLE_CALC_DERIVATIVE
+		if ((flags & GPLE_CALC_DERIVATIVE) && labels && !f->dv) return GPLE_ERR_STATE; // needs a fit built with GPLE_CALC_DERIVATIVE
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		GPLE_HIP(ctx, hipSetDevice(ctx->device));
+		// A predict that drains the stream on a fit the host has not looked at yet looks at it (validate_fit): if the one-launch factorisation had
+		// given up, the fit has been repeated with a launch per panel by then and this predict — whose first pass produced NaN — runs again.
+		bool repeat = false;
+		int status = predict_pass(ctx, f, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars, &repeat);
+		if (status == GPLE_OK && repeat) status = predict_pass(ctx, f, Xs, M, flags, labels, prediction, variance, cutoff_prediction, scalars, &repeat);
+		return status;
+	}
+	static int predict_pass(gple_ctx* ctx, const FitCommon* f, const double* Xs, size_t M, unsigned flags, const double* labels,
+		double* prediction, double* variance, double* cutoff_prediction, gple_predict_scalars* scalars, bool* repeat)
+	{
+		*repeat = false;
+		const bool unvalidated = !f->validated.load();
+		const bool want_deriv = (flags & GPLE_CALC_DERIVATIVE) && labels;
 		hipStream_t st = ctx->stream;
 		const bool dev = flags & GPLE_IO_DEVICE;
 		const bool cplx = f->is_complex;
@@ -1293,11 +1406,27 @@ extern "C"
 		timer_stop(ctx, GPLE_TIMER_PREDICT);
 		// host outputs (and the error scalar) need the stream drained; device-pointer calls without labels stay asynchronous
 		// (pooled scratch is only ever reused by later work on this same stream, which the stream orders)
-		if (flags & PREDICT_NO_SYNC) return GPLE_OK; // internal: the caller drains the stream and reads the scalars itself
-		if (!dev || labels)
+		if ((flags & PREDICT_NO_SYNC) || !(!dev || labels))
+		{
+			// enqueued only (internal NO_SYNC: the caller drains the stream and reads the scalars itself; device pointers without labels): if the
+			// factorisation turns out to have given up, these outputs are NaN and the fit's next synchronising call says so (report_stale_uses)
+			if (unvalidated) f->stale_uses.fetch_add(1);
+			if (flags & PREDICT_NO_SYNC) return GPLE_OK;
+		}
+		else
 		{
 			GPLE_HIP(ctx, hipStreamSynchronize(st));
 			timer_collect(ctx);
+			if (unvalidated)
+			{
+				const long before = ctx->dag_recoveries;
+				GPLE_TRY(validate_fit(ctx, f));
+				if (ctx->dag_recoveries != before)
+				{
+					*repeat = true; // the fit is good now; what this pass computed is NaN
+					return GPLE_OK;
+				}
+			}
 		}
 		if (small_host) // the kernels wrote into the pinned block
 		{
@@ -1386,9 +1515,8 @@ extern "C"
 	// Host side of TrainingComplexKernel's scalar members (see real_fit_finalize).
 	static int complex_fit_finalize(gple_ctx* ctx, gple_complex_fit* f)
 	{
-		hipStream_t st = ctx->stream;
-		GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars, f->sdev, SDEV_N * 8, hipMemcpyDeviceToHost, st));
-		GPLE_HIP(ctx, hipStreamSynchronize(st));
+		const long recoveries_before = ctx->dag_recoveries;
+		GPLE_TRY(validate_fit(ctx, f)); // the scalar block is in the pinned host block now, of a factorisation that completed
 		timer_collect(ctx);
 		const unsigned flags = f->flags;
 		const size_t N = f->N;
@@ -1426,12 +1554,40 @@ extern "C"
 			if (flags & GPLE_CALC_AVERAGE) complex_purity_derivative(theta, h, s, sc.purity_derivative);
 		}
 		f->sc_ready = true;
+		return report_stale_uses(ctx, f, ctx->dag_recoveries != recoveries_before);
+	}
+	// what follows the factorisation of a complex fit: raw sums, purity quadratic forms (+ the derivative members); enqueue only
+	static int complex_fit_post(gple_ctx* ctx, gple_complex_fit* f)
+	{
+		hipStream_t st = ctx->stream;
+		const unsigned flags = f->flags;
+		const double* theta = f->theta;
+		const size_t N = f->N;
+		const double sR = theta[1], lR0 = theta[2], lR1 = theta[3], sI = theta[4], lI0 = theta[5], lI1 = theta[6];
+		hipLaunchKernelGGL(complex_fit_sums_kernel, dim3(1), dim3(1024), 0, st, f->ys, f->v, f->w, f->wx, f->N, f->Np, f->sdev + 1);
+		GPLE_HIP(ctx, hipGetLastError());
+		if (flags & GPLE_CALC_AVERAGE)
+		{
+			// purity quadratic forms in the [Re; Im] weights w = 2 v (complex_kernel.cpp:287-377):
+			// Re(v^H K1 v) + Re(v^T K2 v) = 2 vr'KR'vr + 2 vi'KI'vi + 2 (vr'KC'vr + vi'KC'vi) + 4 vr'(KRC + KIC)vi
+			const ComplexAux a = complex_aux(theta);
+			Scratch part(ctx);
+			const size_t g = (N + 63) / 64;
+			GPLE_HIP(ctx, part.get(g * g));
+			const SEParam aR = purity_aux(sR, lR0, lR1), aI = purity_aux(sI, lI0, lI1), aC = purity_aux(a.sC, a.lC[0], a.lC[1]);
+			const double *wr = f->v, *wi = f->v + f->Np;
+			const SEParam ks[6] = {aR, aI, aC, aC, a.k[3], a.k[4]};
+			const double* as[6] = {wr, wi, wr, wi, wr, wr};
+			const double* bs[6] = {wr, wi, wr, wi, wi, wi};
+			for (int q = 0; q < 6; ++q) GPLE_HIP(ctx, launch_quadform(st, f->Xt, f->N, ks[q], as[q], bs[q], -1, part.p, f->sdev + 8 + q));
+		}
+		if (flags & GPLE_CALC_DERIVATIVE) GPLE_TRY(complex_fit_derivatives(ctx, f, theta, flags));
 		return GPLE_OK;
 	}
 
 	// ---- TrainingComplexKernel ------------------------------------------------------------------------------
-	int gple_complex_fit_create(gple_ctx* ctx, const double theta[8], const double* X, const double* y, size_t N, unsigned flags,
-		gple_complex_fit_scalars* scalars, gple_complex_fit** out)
+	static int complex_fit_create_masked(gple_ctx* ctx, const double theta[8], const double* X, const double* y, size_t N, unsigned flags,
+		unsigned deriv_mask, gple_complex_fit_scalars* scalars, gple_complex_fit** out)
 	{
 		if (!ctx || !theta || !X || !y || !out || N == 0 || N > (1u << 19)) return GPLE_ERR_BAD_ARG;
 		GPLE_OPEN(ctx);
@@ -1457,38 +1613,12 @@ extern "C"
 		f->s0 = s0;
 		build_dspecs(theta, f->dspec);
 		hipStream_t st = ctx->stream;
+		f->deriv_mask = deriv_mask;
 		int status = fit_common(ctx, f, X, y, 2, N, flags);
 		if (status == GPLE_OK)
 		{
-			hipLaunchKernelGGL(complex_fit_sums_kernel, dim3(1), dim3(1024), 0, st, f->ys, f->v, f->w, f->wx, f->N, f->Np, f->sdev + 1);
-			hipError_t e = hipGetLastError();
-			if (e == hipSuccess && (flags & GPLE_CALC_AVERAGE))
-			{
-				// purity quadratic forms in the [Re; Im] weights w = 2 v (complex_kernel.cpp:287-377):
-				// Re(v^H K1 v) + Re(v^T K2 v) = 2 vr'KR'vr + 2 vi'KI'vi + 2 (vr'KC'vr + vi'KC'vi) + 4 vr'(KRC + KIC)vi
-				Scratch part(ctx);
-				const size_t g = (N + 63) / 64;
-				e = part.get(g * g);
-				const SEParam aR = purity_aux(sR, lR0, lR1), aI = purity_aux(sI, lI0, lI1), aC = purity_aux(sC, lC0, lC1);
-				auto mixed = [](double m1, double a0, double a1, double mb, double b0, double b1) { // complex_kernel.cpp:206-219
-					const double prod = (0.5 * (1.0 / (a0 * a0) + 1.0 / (b0 * b0))) * (0.5 * (1.0 / (a1 * a1) + 1.0 / (b1 * b1)));
-					const double m = m1 * mb / std::sqrt(std::sqrt(prod));
-					return make_se(m * m, 0.0, std::sqrt(a0 * a0 + b0 * b0), std::sqrt(a1 * a1 + b1 * b1));
-				};
-				const SEParam aRC = mixed(sR, lR0, lR1, sC, lC0, lC1), aIC = mixed(sI, lI0, lI1, sC, lC0, lC1);
-				const double *wr = f->v, *wi = f->v + f->Np;
-				const SEParam ks[6] = {aR, aI, aC, aC, aRC, aIC};
-				const double* as[6] = {wr, wi, wr, wi, wr, wr};
-				const double* bs[6] = {wr, wi, wr, wi, wi, wi};
-				for (int q = 0; q < 6 && e == hipSuccess; ++q) e = launch_quadform(st, f->Xt, f->N, ks[q], as[q], bs[q], -1, part.p, f->sdev + 8 + q);
-			}
-			if (e == hipSuccess && (flags & GPLE_CALC_DERIVATIVE))
-			{
-				status = complex_fit_derivatives(ctx, f, theta, flags);
-				if (status != GPLE_OK) e = hipErrorUnknown;
-			}
+			status = complex_fit_post(ctx, f);
 			timer_stop(ctx, GPLE_TIMER_FIT);
-			if (e != hipSuccess && status == GPLE_OK) status = record_hip_error(ctx, e, "complex fit reductions", __LINE__);
 		}
 		if (status != GPLE_OK)
 		{
@@ -1508,6 +1638,11 @@ extern "C"
 		}
 		*out = f;
 		return GPLE_OK;
+	}
+	int gple_complex_fit_create(gple_ctx* ctx, const double theta[8], const double* X, const double* y, size_t N, unsigned flags,
+		gple_complex_fit_scalars* scalars, gple_complex_fit** out)
+	{
+		return complex_fit_create_masked(ctx, theta, X, y, N, flags, 0xFFu, scalars, out);
 	}
 	int gple_complex_fit_get_scalars(gple_complex_fit* fit, gple_complex_fit_scalars* out)
 	{
@@ -1551,6 +1686,7 @@ extern "C"
 		const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
 		Scratch tmp(ctx), big(ctx);
 		const dim3 grid2((N + 63) / 64, (N + 3) / 4), blk(256);
+		if (!f->validated.load()) GPLE_TRY(validate_fit(ctx, f)); // (a getter drains the stream anyway)
 		switch (which)
 		{
 		case GPLE_C_KERNEL:
@@ -1732,6 +1868,22 @@ extern "C"
 			if (nblocks && d.owner(nblocks - 1) == rank) n_local -= nblocks * SHARD_BLOCK - M; // owner of the short block: it is the last of its share
 		}
 	} // namespace
+	// Rehearsal transport for ONE rank of a world that is not there (bench.py --emulate-rank r/P on a one-GPU box): ncclAllGather's signature;
+	// `comm` is not a communicator but the number 1 + rank + 256 * world.  This rank's block lands in its slot, the other ranks' slots are
+	// zero-filled (roughly the HBM writes a real gather makes; the fabric's share of the time is what the rehearsal cannot show).
+	int gple_debug_solo_allgather(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, void* hip_stream)
+	{
+		hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+		const size_t code = reinterpret_cast<size_t>(comm);
+		if (datatype != 8 || code < 257) return 4;
+		const size_t world = (code - 1) / 256, rank = (code - 1) % 256;
+		if (rank >= world) return 4;
+		char* dst = static_cast<char*>(recvbuff);
+		const size_t blk = sendcount * sizeof(double);
+		if (rank > 0 && hipMemsetAsync(dst, 0, rank * blk, stream) != hipSuccess) return 1;
+		if (rank + 1 < world && hipMemsetAsync(dst + (rank + 1) * blk, 0, (world - rank - 1) * blk, stream) != hipSuccess) return 1;
+		return hipMemcpyAsync(dst + rank * blk, sendbuff, blk, hipMemcpyDeviceToDevice, stream) == hipSuccess ? 0 : 1;
+	}
 	int gple_set_allgather_function(void* fn)
 	{
 		allgather_override.store(reinterpret_cast<allgather_fn>(fn));
@@ -2196,6 +2348,7 @@ extern "C"
 		// part / nparts > 1 (gple_objective_eval_part): this call forms the N^3 products of the parameters ip with ip % nparts == part (the cheap
 		// first and last parameters belong to part 0) and predicts the rows [lo, hi) of the extra set; the LOOCV error counts on part 0; the
 		// sum over the parts is the whole objective and gradient, make_normal is the caller's after that sum
+		unsigned owned = 0xFFu; // travels with the fit (FitCommon::deriv_mask), not through the context: other threads' fits on this context are not touched
 		if (nparts > 1)
 		{
 			const size_t per = (M_extra + nparts - 1) / nparts, lo = std::min(M_extra, per * part), hi = std::min(M_extra, lo + per);
@@ -2203,19 +2356,8 @@ extern "C"
 			unsigned mask = 0;
 			for (size_t ip = 0; ip < n; ++ip)
 				if ((ip == 0 || ip == n - 1) ? part == 0 : static_cast<int>(ip % nparts) == part) mask |= 1u << ip;
-			std::lock_guard<std::mutex> lk(ctx->mu);
-			ctx->deriv_mask = mask;
+			owned = mask;
 		}
-		struct MaskReset
-		{
-			gple_ctx* c;
-			~MaskReset()
-			{
-				std::lock_guard<std::mutex> lk(c->mu);
-				c->deriv_mask = 0xFFu;
-			}
-		} mask_reset{ctx};
-		const unsigned owned = nparts > 1 ? ctx->deriv_mask : 0xFFu;
 		const unsigned flags = GPLE_CALC_ERROR | (grad ? GPLE_CALC_DERIVATIVE : 0u);
 		gple_predict_scalars ps;
 		double result = 0.0;
@@ -2226,9 +2368,16 @@ extern "C"
 		{
 			gple_real_fit_scalars sc;
 			gple_real_fit* fit = nullptr;
-			GPLE_TRY(gple_real_fit_create(ctx, x, X, y, 1, N, flags | io, nullptr, &fit));
-			int st = gple_real_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io | PREDICT_NO_SYNC | GPLE_PREDICT_FULL, lab, nullptr, nullptr, nullptr, &ps);
+			GPLE_TRY(real_fit_create_masked(ctx, x, X, y, 1, N, flags | io, owned, nullptr, &fit));
+			const unsigned pflags = (flags & GPLE_CALC_DERIVATIVE) | io | PREDICT_NO_SYNC | GPLE_PREDICT_FULL;
+			int st = gple_real_predict(ctx, fit, X_extra, M_extra, pflags, lab, nullptr, nullptr, nullptr, &ps);
 			if (st == GPLE_OK) st = gple_real_fit_get_scalars(fit, &sc); // drains the stream
+			if (st == GPLE_ERR_TIMEOUT && fit->validated.load()) // the factorisation had given up and was repeated: the predict above saw NaN — once more, on the good fit
+			{
+				st = gple_real_predict(ctx, fit, X_extra, M_extra, pflags, lab, nullptr, nullptr, nullptr, &ps);
+				if (st == GPLE_OK) st = gple_ctx_synchronize(ctx); // (the scalars are cached by now: the getter would not drain the stream)
+				if (st == GPLE_OK) st = gple_real_fit_get_scalars(fit, &sc);
+			}
 			gple_real_fit_release(fit);
 			GPLE_TRY(st);
 			if (M_extra) predict_scalars_from_host(ctx, true, want_deriv, false, &ps);
@@ -2240,9 +2389,16 @@ extern "C"
 		{
 			gple_complex_fit_scalars sc;
 			gple_complex_fit* fit = nullptr;
-			GPLE_TRY(gple_complex_fit_create(ctx, x, X, y, N, flags | io, nullptr, &fit));
-			int st = gple_complex_predict(ctx, fit, X_extra, M_extra, (flags & GPLE_CALC_DERIVATIVE) | io | PREDICT_NO_SYNC | GPLE_PREDICT_FULL, y_extra, nullptr, nullptr, nullptr, &ps);
+			GPLE_TRY(complex_fit_create_masked(ctx, x, X, y, N, flags | io, owned, nullptr, &fit));
+			const unsigned pflags = (flags & GPLE_CALC_DERIVATIVE) | io | PREDICT_NO_SYNC | GPLE_PREDICT_FULL;
+			int st = gple_complex_predict(ctx, fit, X_extra, M_extra, pflags, y_extra, nullptr, nullptr, nullptr, &ps);
 			if (st == GPLE_OK) st = gple_complex_fit_get_scalars(fit, &sc);
+			if (st == GPLE_ERR_TIMEOUT && fit->validated.load())
+			{
+				st = gple_complex_predict(ctx, fit, X_extra, M_extra, pflags, y_extra, nullptr, nullptr, nullptr, &ps);
+				if (st == GPLE_OK) st = gple_ctx_synchronize(ctx);
+				if (st == GPLE_OK) st = gple_complex_fit_get_scalars(fit, &sc);
+			}
 			gple_complex_fit_release(fit);
 			GPLE_TRY(st);
 			if (M_extra) predict_scalars_from_host(ctx, true, want_deriv, true, &ps);
@@ -2346,13 +2502,12 @@ extern "C"
 		hipStream_t st = ctx->stream;
 		const int n = static_cast<int>(round_up(N, NPAD));
 		*n_out = n;
-		Scratch L(ctx), work(ctx), part(ctx), u(ctx), w(ctx), info(ctx);
+		Scratch L(ctx), part(ctx), u(ctx), w(ctx), info(ctx);
 		GPLE_HIP(ctx, Xt.get(2 * static_cast<size_t>(n)));
 		GPLE_HIP(ctx, yd.get(n));
 		GPLE_HIP(ctx, T.get(static_cast<size_t>(n) * n));
 		GPLE_HIP(ctx, bvec.get(n));
 		GPLE_HIP(ctx, L.get(static_cast<size_t>(n) * n));
-		GPLE_HIP(ctx, work.get(chol_inverse_work_doubles(n)));
 		GPLE_HIP(ctx, part.get(static_cast<size_t>(n / 256) * n));
 		GPLE_HIP(ctx, u.get(n));
 		GPLE_HIP(ctx, w.get(n));
@@ -2363,8 +2518,30 @@ extern "C"
 		GPLE_HIP(ctx, hipMemsetAsync(T.p, 0, static_cast<size_t>(n) * n * 8, st));
 		GPLE_HIP(ctx, copy_in(st, Xt.p, X, 2 * N, false));
 		GPLE_HIP(ctx, copy_in(st, yd.p, y, N, false));
-		GPLE_HIP(ctx, launch_nlml_gram(st, Xt.p, static_cast<int>(N), n, x, L.p));
-		GPLE_HIP(ctx, chol_inverse_factor(ctx, st, L.p, n, n, T.p, n, reinterpret_cast<int*>(info.p), work.p));
+		// the factorisation's info word is looked at before anything is derived from T (this path synchronises anyway, small N): a give-up of
+		// the one-launch scheme (info = -1) is repeated with one launch per panel, as in recover_fit
+		for (int attempt = 0;; ++attempt)
+		{
+			CholSchemeScope scheme(attempt == 0 ? ctx->chol_scheme : 0);
+			Scratch work(ctx); // sized for the scheme in force
+			GPLE_HIP(ctx, work.get(chol_inverse_work_doubles(n)));
+			GPLE_HIP(ctx, hipMemsetAsync(info.p, 0, 8, st));
+			GPLE_HIP(ctx, launch_nlml_gram(st, Xt.p, static_cast<int>(N), n, x, L.p));
+			GPLE_HIP(ctx, chol_inverse_factor(ctx, st, L.p, n, n, T.p, n, reinterpret_cast<int*>(info.p), work.p));
+			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_NLML + 8, info.p, 8, hipMemcpyDeviceToHost, st));
+			GPLE_HIP(ctx, hipStreamSynchronize(st));
+			int info_i;
+			std::memcpy(&info_i, ctx->host_scalars + HS_NLML + 8, sizeof(int));
+			if (info_i >= 0) break;
+			ctx->dag_giveups += 1;
+			if (attempt == 1)
+			{
+				std::lock_guard<std::mutex> lk(ctx->mu);
+				ctx->last_error = "the factorisation gave up waiting (info = -1) and so did its repetition with one launch per panel";
+				return GPLE_ERR_TIMEOUT;
+			}
+			ctx->dag_recoveries += 1;
+		}
 		GPLE_HIP(ctx, launch_trmv_lower(st, T.p, n, n, yd.p, part.p, u.p));
 		GPLE_HIP(ctx, launch_colpass(st, T.p, n, n, u.p, bvec.p, w.p, 0, nullptr));
 		return GPLE_OK;
@@ -2495,6 +2672,20 @@ extern "C"
 
 	/* gple_debug.h: the layout the factorisation of an n-column matrix will use (host logic only, no device call): outer block bounds
 	 * (0 … n), fork points of the block-row inverse, workspace doubles.  Arrays of `cap` ints; counts come back in nb / nf. */
+	// test knobs of the factorisation on this context; a negative argument leaves that knob as it is.  scheme: 0 = a launch per panel, 1 = one
+	// launch per outer block, 2 = back to GPLE_CHOL_SCHEME; poll_limit: polls before a waiting wave of the one-launch scheme gives up (0: default);
+	// dag_blocks: workgroups of its launches (0: one per CU).  giveups / recoveries (nullable): the context's counters so far.
+	int gple_debug_chol_knobs(gple_ctx* ctx, int scheme, int poll_limit, int dag_blocks, long* giveups, long* recoveries)
+	{
+		if (!ctx) return GPLE_ERR_BAD_ARG;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		if (scheme >= 0) ctx->chol_scheme = scheme >= 2 ? -1 : scheme;
+		if (poll_limit >= 0) ctx->dag_poll_limit = poll_limit;
+		if (dag_blocks >= 0) ctx->dag_blocks = dag_blocks;
+		if (giveups) *giveups = ctx->dag_giveups;
+		if (recoveries) *recoveries = ctx->dag_recoveries;
+		return GPLE_OK;
+	}
 	int gple_debug_chol_layout(int n, int cap, int* bounds, int* nb, int* forks, int* nf, unsigned long long* work_doubles)
 	{
 		if (n <= 0 || n % 64 || !bounds || !nb || !forks || !nf || !work_doubles) return GPLE_ERR_BAD_ARG;

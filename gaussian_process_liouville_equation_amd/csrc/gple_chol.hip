@@ -792,10 +792,18 @@ namespace gple
 		// Hand-over is by flags in global memory, one int per tile quarter (= epoch of the fit that made it final; the buffer is never
 		// cleared), data and flags as agent-scope relaxed atomics (sc1: write-through stores, loads that do not trust another XCD's L2) with
 		// s_waitcnt vmcnt(0) between a quarter's stores and its flag (probes/hop_probe.hip: 1.9 us per hand-over of a tile, 0.55 for a flag alone).
-		// Tasks are dealt round-robin to the waves in an order in which every task depends on earlier ones only (column by column, the rows the
-		// spine needs next first), so with every workgroup resident — the grid never exceeds one per CU — the first unfinished task can always run.
-		// Every wait is bounded: after DAG_POLL_LIMIT polls a wave raises the error flag, everybody leaves, and *info becomes -1.
-		constexpr int DAG_POLL_LIMIT = 1 << 21;
+		// Tasks are drawn from ONE ticket counter in an order in which every task depends on earlier ones only (column by column, the rows the
+		// spine needs next first): whatever a task waits for was drawn before it, by a workgroup that is running, so the launch makes progress with
+		// any number of its worker workgroups resident.  What the argument assumes is that workgroup 0 — the spine, which draws no ticket — is
+		// dispatched no later than the workers that wait for it; HIP dispatches the workgroups of a grid in index order, but does not promise to.
+		// The bounded wait backs that up: after a.poll_limit polls (DAG_POLL_LIMIT_DEFAULT, about 1-2 s) a wave raises the error flag, everybody
+		// leaves, and *info becomes -1; the host then repeats the factorisation with one launch per panel (no waits between workgroups:
+		// gple_capi.hip, recover_fit) — a give-up costs time, never a wrong result.
+		constexpr int DAG_POLL_LIMIT_DEFAULT = 1 << 21;
+		// the ticket floor of a launch is (epoch * DAG_MAX_LAUNCHES + launch number) << 32: a factorisation may have up to DAG_MAX_LAUNCHES launches
+		// (n = 8192: 12; more than 64, the packing of round 3, from n ~ 29k on or with GPLE_CHOL_OUTER=256 above n = 16384 — launch 64 of epoch e then
+		// had the floor of launch 0 of epoch e + 1), and epochs stay below 2^31 / DAG_MAX_LAUNCHES (dag_state)
+		constexpr unsigned long long DAG_MAX_LAUNCHES = 4096;
 #ifndef DAG_POLL_SLEEP
 #define DAG_POLL_SLEEP 8
 #endif
@@ -811,6 +819,7 @@ namespace gple
 			int FS, R;  // block columns of the matrix; block rows of A (one more than FS with the label row)
 			int c0, C1; // the panels of this launch, an outer block of the factorisation: sums start at c0, rows below C1 are spine rows
 			int epoch, nunits, seq; // units of work (tiles: four quarter tasks each); number of this launch within the factorisation
+			int poll_limit;         // polls after which a waiting wave gives up (DAG_POLL_LIMIT_DEFAULT; lowered by the give-up test)
 			long long* stamps; // probe (GPLE_CHOL_DAG_STAMPS): 8 wall-clock stamps per panel of the spine, or nullptr
 			double* pa;        // scratch, one 64 x 64 tile per block row: A~(r, r - 2) before its multiplication by T_{r-2}^T (what the pre-tiles of row r need)
 			int tt_ld;         // tiles per row of Tt (= panels of the launch): tile (r, c) at ((r - c0) * tt_ld + (c - c0)) * 4096
@@ -841,7 +850,7 @@ namespace gple
 			if (h4 != nullptr && (lane & 8)) p = h4 + (lane & 3);
 			if (f1 != nullptr && lane >= 16) p = f1;
 			const int* const err = dag_err(a);
-			for (int it = 0; it < DAG_POLL_LIMIT; ++it)
+			for (int it = 0; it < a.poll_limit; ++it)
 			{
 				const int v = ldf(p);
 				if (__all(v - a.epoch >= 0))
@@ -1213,7 +1222,7 @@ namespace gple
 				// that is running, so the launch makes progress with any number of its workgroups resident (workgroup 0, dispatched first, is
 				// the spine).  The counter is never cleared: every launch raises it to its own floor (epoch, launch number) before drawing.
 				__shared__ int cur_unit;
-				const unsigned long long floor = (static_cast<unsigned long long>(a.epoch) * 64ull + static_cast<unsigned long long>(a.seq)) << 32;
+				const unsigned long long floor = (static_cast<unsigned long long>(a.epoch) * DAG_MAX_LAUNCHES + static_cast<unsigned long long>(a.seq)) << 32;
 				for (;;)
 				{
 					if (t == 0)
@@ -1570,14 +1579,25 @@ namespace gple
 
 	} // namespace
 
+	// scheme of the factorisations issued by this host thread: -1 = the environment's, 0 = step, 1 = dag (CholSchemeScope: the recovery from a
+	// give-up of the one-launch scheme, and the contexts the tests switch by gple_debug_chol_knobs)
+	static thread_local int tl_chol_scheme = -1;
+	CholSchemeScope::CholSchemeScope(int scheme): saved(tl_chol_scheme)
+	{
+		if (scheme >= 0) tl_chol_scheme = scheme;
+	}
+	CholSchemeScope::~CholSchemeScope() { tl_chol_scheme = saved; }
 	static bool chol_dag_scheme()
 	{
 		static const bool v = [] {
 			const char* e = getenv("GPLE_CHOL_SCHEME"); // "step": one launch per panel (rounds 2-3); "dag" (default): one launch per outer block
 			return e == nullptr || std::string(e) != "step";
 		}();
-		return v;
+		return tl_chol_scheme >= 0 ? tl_chol_scheme == 1 : v;
 	}
+	// every layout function below is a pure function of (n, scheme): its cache is keyed by both, so that a factorisation repeated under the other
+	// scheme in the same process lays its work out — and rounds — exactly like a process started with that scheme
+	static long layout_key(int n) { return 2L * n + (chol_dag_scheme() ? 1 : 0); }
 	// Two-level blocking.  A 64-wide panel step that updates the WHOLE trailing matrix reads and writes it once per panel:
 	// 8 n^3 / (3 * 64) bytes in total, 2.9 GB at n = 4096 — the K = 64 updates run at HBM speed, not MFMA speed.  With outer blocks
 	// the panel steps only update the rest of their own block (a strip), and the matrix right of the block gets ONE update with
@@ -1592,21 +1612,21 @@ namespace gple
 			const char* e = getenv("GPLE_CHOL_OUTER");
 			return e ? atoi(e) : -1;
 		}();
-		static const int budget = [] {
+		static const int budget_env = [] {
 			const char* e = getenv("GPLE_CHOL_TILE_BUDGET");
-			if (e && atoi(e) > 0) return atoi(e);
-			// one launch per outer block: the tile tasks of a block are not bound to a panel's duration, wider blocks save trailing updates
-			// (n = 4096: 1.88 / 1.75 / 1.80 ms with 800 / 1600 / 2000; n = 8192: 8.80 / 8.43 / 8.57; one block up to n = 3648)
-			return chol_dag_scheme() ? 1600 : 800;
+			return e && atoi(e) > 0 ? atoi(e) : 0;
 		}();
+		// one launch per outer block: the tile tasks of a block are not bound to a panel's duration, wider blocks save trailing updates
+		// (n = 4096: 1.88 / 1.75 / 1.80 ms with 800 / 1600 / 2000; n = 8192: 8.80 / 8.43 / 8.57; one block up to n = 3648)
+		const int budget = budget_env ? budget_env : (chol_dag_scheme() ? 1600 : 800);
 		static const bool fused = [] {
 			const char* e = getenv("GPLE_CHOL_FUSED");
 			return e == nullptr || atoi(e) != 0;
 		}();
 		static std::mutex mu;
-		static std::map<int, std::vector<int>> cache;
+		static std::map<long, std::vector<int>> cache;
 		std::lock_guard<std::mutex> lk(mu);
-		auto it = cache.find(n);
+		auto it = cache.find(layout_key(n));
 		if (it != cache.end()) return it->second;
 		std::vector<int> b{0};
 		if (forced >= 0 || !fused)
@@ -1629,7 +1649,7 @@ namespace gple
 				if (J0 < n) b.push_back(J0);
 			}
 		b.push_back(n);
-		return cache.emplace(n, std::move(b)).first->second;
+		return cache.emplace(layout_key(n), std::move(b)).first->second;
 	}
 
 	// panel steps of the block columns [j_begin, j_end) (multiples of NB; j_begin on an outer-block boundary or 0) of the n x n matrix
@@ -1644,6 +1664,7 @@ namespace gple
 		int epoch;
 		double* tt; // scratch for the inverse's tiles when the launch forms them (chol_dag_inverse_inside), n * n doubles
 		double* pa; // scratch for the published pre-multiplication tiles (r, r - 2), 64 n doubles
+		int poll_limit = 0, max_blocks = 0; // the context's debug knobs (0: defaults)
 	};
 	namespace
 	{
@@ -1667,7 +1688,7 @@ namespace gple
 				if (atoi(e) >= 2) return atoi(e);
 			int dev = 0, cus = 0;
 			if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2) cus = 64;
-			return cus; // never more workgroups than CUs: every one of them must be resident for the first unfinished task to make progress
+			return cus; // one workgroup per CU: more would only queue behind the resident ones (the ticket order needs no particular number resident)
 		}();
 		return v;
 	}
@@ -1751,6 +1772,7 @@ namespace gple
 			// its panels in one launch, then the matrix right of it in one update
 			const int FS = n / NB, R = FS + (uvec ? 1 : 0);
 			const std::vector<int> cuts = chol_dag_cuts(n, marks);
+			if (cuts.size() > DAG_MAX_LAUNCHES) return hipErrorInvalidValue; // (n > 256k columns: the ticket floor packs the launch number into 12 bits)
 			for (size_t bi = 0; bi + 1 < cuts.size(); ++bi)
 			{
 				const int J0 = cuts[bi], Jend = cuts[bi + 1];
@@ -1758,6 +1780,7 @@ namespace gple
 				DagArgs g{};
 				g.A = A, g.lda = lda, g.T = T, g.ldt = ldt, g.info = info, g.uvec = uvec, g.flags = dag->flags + 4, g.FS = FS, g.R = R;
 				g.c0 = J0 / NB, g.C1 = Jend / NB, g.epoch = dag->epoch;
+				g.poll_limit = dag->poll_limit > 0 ? dag->poll_limit : DAG_POLL_LIMIT_DEFAULT;
 				g.pa = dag->pa;
 				// the whole inverse of a one-block matrix; otherwise the diagonal row block of T of a launch that is exactly one row block of the
 				// inverse — except the first, whose tile tasks are busy enough (chol_block_inverse_inside)
@@ -1772,7 +1795,8 @@ namespace gple
 					return e ? atoi(e) : 64; // 0: no limit.  n = 4096: 1.85 / 1.85 / 1.79 / 1.81 ms with 256 / 128 / 64 / 32 workgroups
 				}();
 				const bool side_busy = marks != nullptr && !marks->empty() && J0 >= marks->front();
-				const int max_blocks = side_busy && late_blocks >= 2 ? std::min(late_blocks, chol_dag_max_blocks()) : chol_dag_max_blocks();
+				const int all_blocks = dag->max_blocks >= 2 ? dag->max_blocks : chol_dag_max_blocks();
+				const int max_blocks = side_busy && late_blocks >= 2 ? std::min(late_blocks, all_blocks) : all_blocks;
 				const int helpers = std::min(max_blocks - 1, g.nunits);
 				constexpr int LAST_STAMP = 11;
 				static const bool want_stamps = getenv("GPLE_CHOL_DAG_STAMPS") != nullptr;
@@ -1912,11 +1936,11 @@ namespace gple
 			ctx->dag_flags_ints = need;
 			ctx->dag_epoch = 0;
 		}
-		// epochs are compared as ints and multiplied by 64 in the high word of the ticket counter: long before either runs out (2^24 factorisations
-		// of one context) the buffer is cleared — in stream order, like everything that uses it — and the count starts again
+		// epochs are compared as ints and multiplied by DAG_MAX_LAUNCHES in the high word of the ticket counter: long before either runs out (2^18
+		// factorisations of one context) the buffer is cleared — in stream order, like everything that uses it — and the count starts again
 		static const int epoch_limit = [] {
 			const char* e = getenv("GPLE_CHOL_DAG_EPOCH_LIMIT"); // (tests)
-			return e && atoi(e) > 0 ? atoi(e) : 1 << 24;
+			return e && atoi(e) > 0 ? std::min(atoi(e), 1 << 18) : 1 << 18;
 		}();
 		if (ctx->dag_epoch >= epoch_limit)
 		{
@@ -1926,6 +1950,7 @@ namespace gple
 		}
 		st.flags = ctx->dag_flags;
 		st.epoch = ++ctx->dag_epoch;
+		st.poll_limit = ctx->dag_poll_limit, st.max_blocks = ctx->dag_blocks;
 		return hipSuccess;
 	}
 
@@ -2030,9 +2055,9 @@ namespace gple
 			return v;
 		}();
 		static std::mutex mu;
-		static std::map<int, std::vector<int>> cache;
+		static std::map<long, std::vector<int>> cache;
 		std::lock_guard<std::mutex> lk(mu);
-		auto it = cache.find(n);
+		auto it = cache.find(layout_key(n));
 		if (it != cache.end()) return it->second;
 		std::vector<int> f;
 		std::vector<int> use = pct;
@@ -2044,7 +2069,7 @@ namespace gple
 			if (*it2 <= 0 || *it2 >= 100 || next - j < 256 || j < 256) continue;
 			f.insert(f.begin(), j), next = j;
 		}
-		return cache.emplace(n, std::move(f)).first->second;
+		return cache.emplace(layout_key(n), std::move(f)).first->second;
 	}
 	// Workspace of chol_inverse_factor, from the fork list actually in use (GPLE_CHOL_FORKS may put the forks anywhere): W = L(g, 0..g0) T(0..g0)
 	// of the widest row block product, the merge tree of the widest side job, the merge tree of the last row block (a tree over b columns needs
@@ -2055,9 +2080,9 @@ namespace gple
 	static const std::vector<int>& chol_marks(int n)
 	{
 		static std::mutex mu;
-		static std::map<int, std::vector<int>> cache;
+		static std::map<long, std::vector<int>> cache;
 		std::lock_guard<std::mutex> lk(mu);
-		auto it = cache.find(n);
+		auto it = cache.find(layout_key(n));
 		if (it != cache.end()) return it->second;
 		std::vector<int> m;
 		const std::vector<int>& forks = chol_fork_points(n);
@@ -2079,7 +2104,7 @@ namespace gple
 				std::sort(m.begin(), m.end());
 			}
 		}
-		return cache.emplace(n, std::move(m)).first->second;
+		return cache.emplace(layout_key(n), std::move(m)).first->second;
 	}
 	struct InvWork
 	{

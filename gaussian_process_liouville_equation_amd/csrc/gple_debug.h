@@ -4,7 +4,7 @@
  *   tests/test_gpu_chol_diag.py, probes/step_probe.py -> gple_debug_potrf_step
  *   tests/test_host_logic.py                          -> gple_debug_chol_layout (no device call)
  *   tests/test_gpu_gemm.py                            -> gple_debug_gemm
- *   tests/test_gpu_chol_diag.py                       -> gple_debug_side_stream */
+ *   tests/test_gpu_chol_diag.py                       -> gple_debug_side_stream, gple_debug_chol_knobs (the give-up test) */
 #ifndef GPLE_DEBUG_H
 #define GPLE_DEBUG_H
 #include "../../include/gple.h"
@@ -28,6 +28,15 @@ extern "C"
 	/* The side stream the context's fits run their block-row inverse on (created by the first fit with n >= 1024): how many candidate streams
 	 * were tried until one ran beside the main stream, and whether the chosen one did (0: none did, or no fit has needed one yet). */
 	int gple_debug_side_stream(gple_ctx* ctx, int* attempts, int* overlaps);
+	/* A transport for gple_set_allgather_function() that stands in for a world that is not there: rank r of P on a one-GPU box (bench.py
+	 * --emulate-rank r/P).  Pass (void*)(1 + r + 256 * P) as the communicator: this rank's block is copied into its slot of the gathered buffer,
+	 * the other slots are zero-filled.  What the rank computes, enqueues and unpacks is what a real rank does; the fabric is missing. */
+	int gple_debug_solo_allgather(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, void* hip_stream);
+	/* Test knobs of the factorisation on ONE context; a negative argument leaves its knob alone.  scheme: 0 = a launch per panel (what
+	 * GPLE_CHOL_SCHEME=step selects process-wide), 1 = one launch per outer block, 2 = back to the environment's; poll_limit: polls before a waiting
+	 * wave of the one-launch scheme gives up (0 = the default, 2^21); dag_blocks: workgroups of its launches (0 = one per CU).  giveups / recoveries
+	 * (nullable): how often the host has seen info = -1 on this context / repeated a factorisation with a launch per panel because of it. */
+	int gple_debug_chol_knobs(gple_ctx* ctx, int scheme, int poll_limit, int dag_blocks, long* giveups, long* recoveries);
 #ifdef __cplusplus
 }
 #endif

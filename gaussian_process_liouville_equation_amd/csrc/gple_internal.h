@@ -76,7 +76,6 @@ namespace gple
 		// second stream + two events for the part of a fit that does not sit on the factorisation's critical path (created on
 		// first use by chol_inverse_factor; the main stream waits for the side work before anything reads its results)
 		hipStream_t side_stream = nullptr;
-		unsigned deriv_mask = 0xFFu; // which parameters' N^3 products a derivative fit forms (bit ip; gple_objective_eval_part splits them over ranks)
 		int side_attempts = 0;       // candidate streams tried until one ran beside the main stream (pick_side_stream)
 		bool side_overlaps = false;  // the chosen one did
 		hipEvent_t side_join = nullptr;
@@ -84,6 +83,10 @@ namespace gple
 		int* dag_flags = nullptr;
 		size_t dag_flags_ints = 0;
 		int dag_epoch = 0;
+		// debug knobs of the factorisation (gple_debug_chol_knobs; the give-up test): scheme of this context's fits (-1: GPLE_CHOL_SCHEME, 0: a launch
+		// per panel, 1: one launch per outer block), polls before a wave of the one-launch scheme gives up, workgroups of its launches (0: defaults)
+		int chol_scheme = -1, dag_poll_limit = 0, dag_blocks = 0;
+		long dag_giveups = 0, dag_recoveries = 0; // give-ups seen by the host / factorisations repeated with a launch per panel because of one
 		std::vector<hipEvent_t> side_forks;
 		// pinned host block for scalar results
 		double* host_scalars = nullptr;
@@ -154,6 +157,14 @@ namespace gple
 	// diagonal blocks of the factor are never stored: on return T (n x n, ldt) holds inv(L_jj) in every diagonal block (full
 	// 64 x 64 blocks, zeros above the diagonal), i.e. the diagonal blocks of T = L^-1 (potrf_diag_kernel).  info (device int): 0 or 1 + index of the
 	// first non-positive pivot.
+	// the scheme of the factorisations this host thread issues while the object lives (scheme < 0: unchanged)
+	struct CholSchemeScope
+	{
+		explicit CholSchemeScope(int scheme);
+		~CholSchemeScope();
+		CholSchemeScope(const CholSchemeScope&) = delete;
+		int saved;
+	};
 	hipError_t potrf_lower(hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* uvec = nullptr, Ctx* ctx = nullptr,
 		double* tt = nullptr, double* pa = nullptr); // pa: 64 n doubles of scratch (without: a launch per panel); tt: n * n doubles — the launch also completes T = L^-1
 	hipError_t debug_potrf_diag(hipStream_t s, const double* A, double* T, int* info, long long* stamps);

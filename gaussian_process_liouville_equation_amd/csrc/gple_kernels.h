@@ -34,8 +34,9 @@ namespace gple
 	// u = T * ys (lower triangular T, n x n): partial sums then reduction. part: (n/256) * n doubles.
 	hipError_t launch_trmv_lower(hipStream_t s, const double* T, long ldt, int n, const double* ys, double* part, double* u);
 	// v[k] = sum_i T(i,k) u[i],  w[k] = sum_i T(i,k)^2 ; optionally wx[k] = sum_i T(i,k) T(i,k+shift) (complex: diag of Mxy).
+	// info != nullptr: a negative *info (the factorisation gave up, gple_chol.hip) turns v, w, wx into NaN
 	hipError_t launch_colpass(hipStream_t s, const double* T, long ldt, int n, const double* u, double* v, double* w, int shift,
-		double* wx);
+		double* wx, const int* info = nullptr);
 	// raw sums for the real fit: out[0]=sum (v/w)^2, out[1]=sum v, out[2]=sum x v, out[3]=sum p v, out[4]=sum ys v
 	// out[0..4]: the five sums of a real fit; qpart != nullptr: also *qout = sum of the nq per-block partials of a quadratic form
 	// (launch_quadform_partials), saving the separate reduction launch

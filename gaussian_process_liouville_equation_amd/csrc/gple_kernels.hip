@@ -158,8 +158,10 @@ namespace gple
 		}
 
 		// one wave per column of the lower-triangular T
+		// info != nullptr and *info < 0 (a wave of the one-launch factorisation gave up waiting, gple_chol.hip): T is then unfinished — finite, but
+		// wrong — and every product of this pass is replaced by NaN, so that whatever is enqueued behind the fit yields NaN, never a plausible number
 		__global__ void __launch_bounds__(256) colpass_kernel(const double* __restrict__ T, long ldt, int n, const double* __restrict__ u,
-			double* __restrict__ v, double* __restrict__ w, int shift, double* __restrict__ wx)
+			double* __restrict__ v, double* __restrict__ w, int shift, double* __restrict__ wx, const int* __restrict__ info)
 		{
 			const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 			const double* __restrict__ c = T + static_cast<long>(k) * ldt;
@@ -175,6 +177,7 @@ namespace gple
 				if (cross && i >= i2) ax = fma(tv, c2[i], ax);
 			}
 			av = wave_sum(av), aw = wave_sum(aw), ax = wave_sum(ax);
+			if (info != nullptr && *info < 0) av = aw = ax = __builtin_nan("");
 			if (lane == 0)
 			{
 				v[k] = av;
@@ -326,6 +329,8 @@ namespace gple
 			}
 		}
 
+		// the fit's scalar block: [0] rescale factor, [31] info of the factorisation (an int in the double's slot; gple_capi.hip SDEV_INFO)
+		__device__ __forceinline__ bool fit_gave_up(const double* s_dev) { return *reinterpret_cast<const int*>(s_dev + 31) < 0; }
 		// PredictiveKernel epilogue (kernel.cpp:496-522)
 		__global__ void __launch_bounds__(256) predict_finish_real_kernel(const double* __restrict__ q, const double* __restrict__ mu, int M,
 			double self, const double* __restrict__ s_dev, const double* __restrict__ labels, double* __restrict__ mean,
@@ -334,10 +339,11 @@ namespace gple
 			__shared__ double red[4];
 			const int i = blockIdx.x * 256 + threadIdx.x;
 			const double s = *s_dev;
+			const bool bad = fit_gave_up(s_dev); // the mean is NaN already (colpass_kernel); the variance comes from the unfinished T: NaN too
 			double e = 0.0;
 			if (i < M)
 			{
-				const double m = mu[i], vv = self - q[i];
+				const double m = mu[i], vv = bad ? __builtin_nan("") : self - q[i];
 				const double cf = cutoff_value(m * m, fabs(m), vv);
 				if (mean) mean[i] = m;
 				if (var) var[i] = vv;
@@ -363,11 +369,12 @@ namespace gple
 			__shared__ double red[4];
 			const int i = blockIdx.x * 256 + threadIdx.x;
 			const double s = *s_dev;
+			const bool bad = fit_gave_up(s_dev);
 			double e = 0.0;
 			if (i < M)
 			{
 				const double re = mu[i], im = mu[m_split + i];
-				const double vv = self - (q[i] + q[m_split + i]);
+				const double vv = bad ? __builtin_nan("") : self - (q[i] + q[m_split + i]);
 				const double cf = cutoff_value(re * re + im * im, hypot(re, im), vv);
 				if (mean) mean[2 * i] = re, mean[2 * i + 1] = im;
 				if (var) var[i] = vv;
@@ -403,9 +410,9 @@ namespace gple
 		hipLaunchKernelGGL(trmv_reduce_kernel, dim3(n / 256), dim3(256), 0, s, part, n, u);
 		return hipGetLastError();
 	}
-	hipError_t launch_colpass(hipStream_t s, const double* T, long ldt, int n, const double* u, double* v, double* w, int shift, double* wx)
+	hipError_t launch_colpass(hipStream_t s, const double* T, long ldt, int n, const double* u, double* v, double* w, int shift, double* wx, const int* info)
 	{
-		hipLaunchKernelGGL(colpass_kernel, dim3(n / 4), dim3(256), 0, s, T, ldt, n, u, v, w, shift, wx);
+		hipLaunchKernelGGL(colpass_kernel, dim3(n / 4), dim3(256), 0, s, T, ldt, n, u, v, w, shift, wx, info);
 		return hipGetLastError();
 	}
 	hipError_t launch_real_fit_sums(hipStream_t s, const double* Xt, const double* ys, const double* v, const double* w, int N, double* out,

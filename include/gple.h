@@ -35,6 +35,15 @@ extern "C" {
 #define GPLE_ERR_ALLOC 3
 #define GPLE_ERR_COLLECTIVE 5 /* RCCL could not be resolved or a collective failed (gple_ctx_last_error has the text) */
 #define GPLE_ERR_STATE 4 /* e.g. derivative output requested from a fit built without GPLE_CALC_DERIVATIVE; call on a destroyed context */
+/* The factorisation of a fit runs as ONE launch per block of panels whose workgroups hand tiles to each other through flags; every wait is bounded
+ * (about a second), and a wave that gives up leaves the launch unfinished.  That never yields a wrong number: on the device everything derived
+ * from the unfinished factor becomes NaN, and the first call on the fit that drains the stream (*_fit_create with a scalars struct,
+ * *_fit_get_scalars, *_fit_get, a predict with host pointers or labels, the objective and NLML entry points) notices, repeats the
+ * factorisation with one launch per panel (no waits between workgroups) and returns the correct result — the caller sees nothing but the delay.
+ * GPLE_ERR_TIMEOUT is returned only (a) by such a draining call when OTHER calls had been enqueued on the fit before it (device pointers, no labels:
+ * those never drain the stream) — their outputs are NaN, the fit is valid from here on, gple_ctx_last_error says how many to repeat; or
+ * (b) when the repetition failed as well (it cannot give up: it has no waits). */
+#define GPLE_ERR_TIMEOUT 6
 
 /* The three bools of the Training*Kernel constructors (kernel.h:128-134, complex_kernel.h:167-173). */
 #define GPLE_CALC_ERROR 0x1u
@@ -68,8 +77,8 @@ typedef struct gple_real_fit_scalars {
 	double error_derivative[4];      /* get_error_derivative          kernel.cpp:381-400           */
 	double population_derivative[4]; /* get_population_derivative     kernel.cpp:401-435           */
 	double purity_derivative[4];     /* get_purity_derivative         kernel.cpp:436-477           */
-	int info;                        /* 0: factorisation fine; k>0: non-positive pivot met at column k; -1: a workgroup of the factorisation gave up
-	                                    waiting for another (2^21 polls, about a second: a GPU held by other work for that long) — results invalid */
+	int info;                        /* 0: factorisation fine; k>0: non-positive pivot met at column k (NaN propagates, as in the reference).  Never -1 in a
+	                                    struct a call returned with GPLE_OK: a give-up of the one-launch factorisation is recovered from first (GPLE_ERR_TIMEOUT above) */
 } gple_real_fit_scalars;
 
 /* Scalar getters of TrainingComplexKernel. */

@@ -262,3 +262,146 @@ def test_inverse_in_the_launch_against_the_merge_trees():
     for N in sizes:
         assert np.abs(a["v%d" % N] - b["v%d" % N]).max() <= 1e-7 * np.abs(b["v%d" % N]).max(), N
         assert abs(a["e%d" % N] - b["e%d" % N]) <= 1e-7 * b["e%d" % N], N
+
+
+# ---- a give-up of the one-launch factorisation must end in the correct result ---------------------------
+def _knobs(api, scheme=-1, poll_limit=-1, dag_blocks=-1):
+    """gple_debug_chol_knobs: per-context scheme (0 step, 1 dag, 2 environment), poll limit and workgroup count; returns (giveups, recoveries)"""
+    g, r = ctypes.c_long(), ctypes.c_long()
+    api.lib.gple_debug_chol_knobs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
+    assert api.lib.gple_debug_chol_knobs(api.ctx, scheme, poll_limit, dag_blocks, ctypes.byref(g), ctypes.byref(r)) == 0
+    return g.value, r.value
+
+
+def _fit_signature(api, cplx, theta, X, y, Xs, flags=3, defer=False):
+    from gaussian_process_liouville_equation_amd import _capi as c
+    f = (api.complex_fit if cplx else api.real_fit)(theta, X, y, flags, defer_scalars=defer)
+    p = (api.complex_predict if cplx else api.real_predict)(f, Xs)  # host pointers: drains the stream
+    sc = dict(f.scalars)
+    sig = {"v": f.get(c.C_INVLBL if cplx else c.R_INVLBL).tobytes(), "mean": p["prediction"].tobytes(), "var": p["variance"].tobytes(), "cut": p["cutoff"].tobytes(),
+           "error": sc["error"], "purity": sc["purity"], "info": sc["info"]}
+    if flags & 4:
+        sig["derr"] = np.asarray(sc["error_derivative"]).tobytes()
+        sig["dpur"] = np.asarray(sc["purity_derivative"]).tobytes()
+    f.release()
+    return sig
+
+
+@pytest.mark.parametrize("cplx,N,flags", [(False, 600, 3), (False, 1500, 7), (False, 4200, 3), (True, 700, 3), (True, 300, 7)])
+def test_a_give_up_of_the_one_launch_factorisation_is_recovered_bit_for_bit(cplx, N, flags):
+    """potrf_dag_kernel waits on flags with a bounded number of polls; a wave that gives up sets info = -1 and leaves T unfinished.  The host must
+    then end in the CORRECT result: the same fit repeated with one launch per panel (recover_fit).  The give-up is forced deterministically: one worker
+    workgroup and a poll limit of 2 — the first tile task waits for the spine's T_0 for microseconds and gives up at once.  The recovered fit must
+    equal, bit for bit, the fit of a context that runs the launch-per-panel scheme from the start: scalars, weights, derivative members, and a predict
+    (mean, variance, cut-off) on a handful of points.  Sizes: one outer block with the inverse inside the launch (n = 768, 1536), several launches and
+    the side stream (n = 4352), complex (n = 1536, 768), with and without derivative members (W and dv are rebuilt from the repeated factor)."""
+    import gaussian_process_liouville_equation_amd as pkg
+    from tests.test_gpu_configs import config_inputs, THETA_R, THETA_C
+    X, y, _, _ = config_inputs(N, 8, 1, cplx=cplx)
+    Xs = X[:: max(1, N // 40)] + 0.05
+    theta = THETA_C if cplx else THETA_R
+    ref_api, bad_api = pkg.open_api(0), pkg.open_api(0)
+    try:
+        _knobs(ref_api, scheme=0)
+        ref = _fit_signature(ref_api, cplx, theta, X, y, Xs, flags)
+        assert ref["info"] == 0 and np.isfinite(ref["error"])
+        _knobs(bad_api, scheme=1, poll_limit=2, dag_blocks=2)
+        # (a) scalars requested at creation: the create call itself notices and recovers
+        got = _fit_signature(bad_api, cplx, theta, X, y, Xs, flags)
+        g, r = _knobs(bad_api)
+        assert g >= 1 and r >= 1, "the give-up was not provoked: the test proves nothing"
+        assert got == ref
+        # (b) deferred scalars: the first call that drains the stream — here the predict with host pointers — notices, recovers and runs again
+        got = _fit_signature(bad_api, cplx, theta, X, y, Xs, flags, defer=True)
+        assert _knobs(bad_api)[1] >= r + 1
+        assert got == ref
+        # the same context with sane knobs again: the one-launch scheme's own result, no further recovery
+        _knobs(bad_api, scheme=2, poll_limit=0, dag_blocks=0)
+        before = _knobs(bad_api)
+        dag = _fit_signature(bad_api, cplx, theta, X, y, Xs, flags)
+        assert _knobs(bad_api) == before and dag["info"] == 0
+        assert abs(dag["error"] - ref["error"]) <= 1e-7 * abs(ref["error"])
+    finally:
+        ref_api.close()
+        bad_api.close()
+
+
+def test_work_enqueued_before_the_give_up_was_noticed_is_nan_and_reported():
+    """A fit created without a scalars struct and a predict with DEVICE pointers only enqueue work: nobody has looked at the factorisation when the
+    predict runs.  If it had given up, the predict's outputs must be NaN (never numbers from the unfinished factor), the next draining call on the fit
+    (gple_real_fit_get_scalars) must recover the fit AND say that earlier work has to be repeated (GPLE_ERR_TIMEOUT), and the repeated predict must
+    then equal the launch-per-panel result bit for bit."""
+    import torch
+
+    import gaussian_process_liouville_equation_amd as pkg
+    from gaussian_process_liouville_equation_amd import _capi as c
+    from tests.test_gpu_configs import config_inputs, THETA_R
+    N = 1500
+    X, y, _, _ = config_inputs(N, 8, 1)
+    Xs = np.ascontiguousarray(X[::30] + 0.05)
+    M = len(Xs)
+    ref_api, api = pkg.open_api(0), pkg.open_api(0)
+    try:
+        _knobs(ref_api, scheme=0)
+        ref = _fit_signature(ref_api, False, THETA_R, X, y, Xs)
+        _knobs(api, scheme=1, poll_limit=2, dag_blocks=2)
+        f = api.real_fit(THETA_R, X, y, 3, defer_scalars=True)
+        dXs = torch.from_numpy(Xs).cuda()
+        out = torch.zeros(3, M, dtype=torch.float64, device="cuda")
+        dp = lambda t: ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_double))
+        ps = c.PredictScalars()
+
+        def predict():
+            return api.lib.gple_real_predict(api.ctx, f.handle, dp(dXs), M, c.IO_DEVICE, None, dp(out[0]), dp(out[1]), dp(out[2]), ctypes.byref(ps))
+
+        assert predict() == 0
+        api.synchronize()
+        assert bool(torch.isnan(out).all()), "a predict on a given-up factor returned numbers"
+        sc = c.RealFitScalars()
+        st = api.lib.gple_real_fit_get_scalars(f.handle, ctypes.byref(sc))
+        assert st == c.GPLE_ERR_TIMEOUT, st
+        assert b"repeat" in api.lib.gple_ctx_last_error(api.ctx)
+        assert api.lib.gple_real_fit_get_scalars(f.handle, ctypes.byref(sc)) == 0  # the fit itself is good now
+        assert sc.info == 0 and sc.error == ref["error"] and sc.purity == ref["purity"]
+        assert predict() == 0
+        api.synchronize()
+        got = out.cpu().numpy()
+        assert got[0].tobytes() == ref["mean"] and got[1].tobytes() == ref["var"] and got[2].tobytes() == ref["cut"]
+        f.release()
+    finally:
+        ref_api.close()
+        api.close()
+
+
+def test_objective_and_nlml_recover_from_a_give_up():
+    """loose_function (fit + predict of the extra points enqueued in one go, one synchronisation) and the NLML path must return the launch-per-panel
+    values when the one-launch factorisation gives up under them — not NaN mapped to DBL_MAX by make_normal, not numbers from an unfinished factor."""
+    import gaussian_process_liouville_equation_amd as pkg
+    from tests import parity
+    from tests.test_gpu_configs import config_inputs, THETA_R, THETA_C
+    ref_api, api = pkg.open_api(0), pkg.open_api(0)
+    try:
+        _knobs(ref_api, scheme=0)
+        _knobs(api, scheme=1, poll_limit=2, dag_blocks=2)
+        for cplx, N in ((False, 900), (True, 400)):
+            X, y, _, _ = config_inputs(N, 8, 1, cplx=cplx)
+            rng = np.random.default_rng(3)
+            Xe = X[np.arange(2 * N) % N] + rng.normal(0, 0.3, size=(2 * N, 2))
+            ye = (np.exp(-0.5 * (((Xe[:, 0] + 10) / 0.7086) ** 2 + ((Xe[:, 1] - 14.112) / 0.7056) ** 2)) / (2 * np.pi * 0.7086 * 0.7056)).astype(complex)
+            theta = THETA_C if cplx else THETA_R
+            r0 = _knobs(api)[1]
+            vr, gr = ref_api.loose_function(theta, X, np.asarray(y, dtype=complex), Xe, ye)
+            v, g = api.loose_function(theta, X, np.asarray(y, dtype=complex), Xe, ye)
+            assert _knobs(api)[1] > r0, "the give-up was not provoked"
+            assert np.isfinite(vr) and vr < 1e300
+            assert v == vr and g.tobytes() == gr.tobytes()
+        X, y, _ = parity.synthetic_real(700, 8, 99)
+        x = [0.05, 1.3, 1.0 / 0.7086, 1.0 / 0.7056]
+        r0 = _knobs(api)[1]
+        vr, gr = ref_api.nlml(x, X, y)
+        v, g = api.nlml(x, X, y)
+        assert _knobs(api)[1] > r0
+        assert v == vr and np.asarray(g).tobytes() == np.asarray(gr).tobytes()
+    finally:
+        ref_api.close()
+        api.close()

@@ -399,6 +399,51 @@ def test_three_level_tick_through_the_step_loop(gpu):
     assert abs(k1.calculate_purity() - pur0) <= 0.10 * abs(pur0)
 
 
+def test_three_level_tick_at_c5_size(gpu):
+    """configs[4] AS STATED: "3-state PES ... N = 8192 ... full step loop" — one tick of main.cpp:143-176 for a three-level system at N = 8192
+    points per element: six elements (3 real + 3 complex GPs, n = 8192 / 16384), 36 back-propagated predicts per point (gple_evolve_n), the
+    density and an extra set of N points per element evolved (bench.py --workload C5step3 times the tick with the full 5N extra points:
+    profiles/r04_bench/C5step3.json), then six refits.  The reference asserts for NumPES > 2 (evolve.cpp:367-371), so what is checked is what the
+    two-level test at this size checks: population and purity of the refitted kernels within the drift the reference tolerates before it
+    re-optimises (main.cpp:179-188; population 2 %, purity 10 %), coordinates moved by the classical step, and the batched tick equal to the
+    same tick on 8 spot-checked points alone (the few-points predict path) to the accuracy two routes through the GP predict allow."""
+    from gaussian_process_liouville_equation_amd import steploop
+    N, xc = 8192, -0.5
+    rng = np.random.Generator(np.random.PCG64(20240607 + 9))
+    weight = (0.5, 0.3, 0.2)
+    order = K.element_order(3)
+    dens, extra = {}, {}
+    for (i, j) in order:
+        for store in (dens, extra):
+            r = rng.normal([xc, 14.112], [0.7086, 0.7056], size=(N, 2))
+            g = np.exp(-0.5 * (((r[:, 0] - xc) / 0.7086) ** 2 + ((r[:, 1] - 14.112) / 0.7056) ** 2)) / (2 * np.pi * 0.7086 * 0.7056)
+            amp = weight[i] if i == j else 0.6 * np.sqrt(weight[i] * weight[j]) * np.exp(0.4j * (r[:, 0] - xc) + 0.3j * (i + j))
+            store[(i, j)] = (r, (g * amp).astype(complex))
+    params = {e: (TH if e[0] == e[1] else THC) for e in order}
+    k0 = K.TrainingKernels(params, K.construct_training_sets(dens, 3), True, True, False, api=gpu, num_pes=3)
+    pop0, pur0 = k0.calculate_population(), k0.calculate_purity()
+    assert abs(pop0 - 1.0) <= 0.02
+    # purity = 2 pi int g^2 (sum_k w_k^2 + 2 sum_{k<l} 0.36 w_k w_l) with 2 pi int g^2 = 1 / (2 sx sp) = 1.00: 0.38 + 0.72 * 0.31 = 0.6032
+    assert abs(pur0 - 0.6032) <= 0.03 * 0.6032, pur0
+    d1, x1, k1 = steploop.tick(dens, extra, params, MASS, DT, k0, steploop.TSAC)
+    for e in order:
+        assert d1[e][0].shape == dens[e][0].shape and x1[e][0].shape == extra[e][0].shape
+        assert np.all(np.isfinite(d1[e][1])) and np.all(np.isfinite(x1[e][1]))
+        assert np.abs(d1[e][0][:, 0] - dens[e][0][:, 0] - dens[e][0][:, 1] * DT / MASS).max() <= 1e-3
+    pop1, pur1 = k1.calculate_population(), k1.calculate_purity()
+    assert abs(pop1 - pop0) <= 0.02 * abs(pop0), (pop0, pop1)
+    assert abs(pur1 - pur0) <= 0.10 * abs(pur0), (pur0, pur1)
+    for k in range(3):  # populations stay real
+        assert np.abs(d1[(k, k)][1].imag).max() <= 1e-9 * np.abs(d1[(k, k)][1]).max()
+    idx = rng.choice(N, 8, replace=False)
+    sub = {e: (dens[e][0][idx], dens[e][1][idx]) for e in order}
+    s1 = steploop.evolve(sub, MASS, DT, k0, steploop.TSAC)
+    for e in order:
+        assert np.array_equal(s1[e][0], d1[e][0][idx])
+        scale = np.abs(dens[e][1]).max()
+        assert np.abs(s1[e][1] - d1[e][1][idx]).max() <= 1e-8 * scale, e
+
+
 def test_three_level_main_tick_with_elements_appearing(gpu):
     """steploop.main_tick for a three-level system (the reference's loop of main.cpp:136-186 compiled for NumPES = 3, where it asserts): all
     population on the lowest state just before the three-state crossing of the library's model; is_very_small asks the N-level new-point
