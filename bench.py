@@ -41,6 +41,10 @@ WORKLOADS = {  # name: (N, G, kernel)
     "C5step": (8192, 0, "step"),    # the same at the N of configs[4] (two-level physics: what the reference instantiates)
     "C2step3": (1024, 0, "step3"),  # one tick of a THREE-level system (6 elements, 36 back-propagated predicts per point: gple_evolve_n) at N = 1024
     "C5step3": (8192, 0, "step3"),  # configs[4] as stated: 3-state PES, full step loop, N = 8192
+    # the log-marginal-likelihood formulation north_star names (test/gpr.cpp:499-532, 654-706), at the N of configs[1] / configs[3]:
+    # one step = NLML value + gradient, then the mean-only prediction on a 256 x 256 grid (each builds and factors K, like the reference's two functions)
+    "NLML1024": (1024, 256, "nlml"),
+    "NLML4096": (4096, 256, "nlml"),
 }
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak; measured 78.4 with v_mfma_f64_16x16x4_f64
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
@@ -369,6 +373,8 @@ def main():
         return opt_loop(args, pkg, c, parallel, torch, dist, rank, world, dev)
     if WORKLOADS[args.workload][2] in ("step", "step3"):
         return step_loop(args, pkg, torch, dist, rank, world, dev)
+    if WORKLOADS[args.workload][2] == "nlml":
+        return nlml_step(args, pkg, c, torch, dist, rank, world, dev)
 
     N, G, kernel = WORKLOADS[args.workload]
     cplx = kernel == "complex"
@@ -855,6 +861,104 @@ def step_loop(args, pkg, torch, dist, rank, world, dev):
                      "note": "whole-tick rate: contraction flops of the predicts / tick time (fits, K* generation and the host round trips of the Python mirror included)"},
         "population_after": pop,
     }
+    if rank == 0:
+        emit(result)
+    api.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def nlml_step(args, pkg, c, torch, dist, rank, world, dev):
+    """--workload NLML1024 | NLML4096: negative_log_marginal_likelihood (value + trace gradient, test/gpr.cpp:499-532) followed by predict_phase
+    (mean-only prediction k*(x) K^-1 y on a 256 x 256 grid, :654-706) — both build and factor K, as the reference's two functions do.  Kernel =
+    w_d^2 Diag + w_g^2 GaussianARD (NOCROSS build: diagonal weights = inverse lengths).  The dominant work is the factorisation and the inverse
+    factor (N^3 / 3 each, twice per step) plus T^T T for the gradient (N^3 / 3): fp64 MFMA; the prediction is M N exponentials: fp64 VALU.
+    Single GPU (replicas with --gpus N)."""
+    N, G, _ = WORKLOADS[args.workload]
+    M = G * G
+    X, y, _, _ = synthetic(N, 1, 20240607 + 70 + rank, "real")
+    gx, gp = np.meshgrid(np.linspace(-13.0, -7.0, G), np.linspace(11.0, 17.0, G), indexing="ij")
+    grid = np.ascontiguousarray(np.stack([gx.ravel(), gp.ravel()], axis=1))
+    x = np.array([0.05, 1.3, 1.0 / 0.7086, 1.0 / 0.7056])  # (w_d, w_g, a_x, a_p): initial ARD weight = 1 / sigma (test/gpr.cpp:167-173)
+    api = pkg.open_api(dev)
+    api.enable_timing(True)
+    dgrid = torch.from_numpy(grid).cuda()
+    dmean = torch.empty(M, dtype=torch.float64, device="cuda")
+    dp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))
+    hp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    Xc, yc = np.ascontiguousarray(X), np.ascontiguousarray(y)
+    val, grad = C.c_double(), np.zeros(4)
+    api.lib.gple_nlml.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 3 + [C.c_size_t] + [C.POINTER(C.c_double)] * 2
+    api.lib.gple_nlml_predict.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 3 + [C.c_size_t, C.POINTER(C.c_double), C.c_size_t, C.c_uint, C.POINTER(C.c_double)]
+
+    def step():
+        st = api.lib.gple_nlml(api.ctx, hp(x), hp(Xc), hp(yc), N, C.cast(C.byref(val), C.POINTER(C.c_double)), hp(grad))
+        if st == 0:
+            st = api.lib.gple_nlml_predict(api.ctx, hp(x), hp(Xc), hp(yc), N, dp(dgrid), M, c.IO_DEVICE, dp(dmean))
+        if st != 0:
+            raise RuntimeError(api.lib.gple_ctx_last_error(api.ctx).decode())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    api.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.control == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not (np.isfinite(val.value) and np.all(np.isfinite(grad)) and bool(torch.isfinite(dmean).all())):
+        raise RuntimeError("non-finite NLML value, gradient or prediction")
+    ms = 1e3 * elapsed / args.steps
+    _, f_total, f_cnt = api.timing(0)  # HIP events around chol_inverse_factor: L = chol(K) and T = L^-1 (two per step)
+    _, p_total, p_cnt = api.timing(1)  # around the prediction kernels
+    n = -(-N // 256) * 256
+    f_ms = f_total / max(1, f_cnt)
+    fl = 2.0 * float(n) ** 3 / 3.0  # N^3 / 3 (factor) + N^3 / 3 (inverse factor)
+    achieved = fl / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
+    p_ms = p_total / max(1, p_cnt)
+    result = {
+        "metric": "GP fit+predict ms/step (N samples, M grid pts)", "value": round(ms, 4), "unit": "ms/step", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: negative log marginal likelihood value + gradient (test/gpr.cpp:499-532), then mean-only prediction on a {G}x{G} grid "
+                               f"(:654-706), N={N}, Diag + GaussianARD kernel (NOCROSS)", "N": N, "M": M,
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
+        "roofline": {"bound": "mfma", "kernel": "chol_inverse_factor: potrf_dag_kernel launches + the GEMMs of the block-row inverse (L = chol(K), T = L^-1)",
+                     "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel_ms": round(f_ms, 4), "launches_per_step": f_cnt / max(1, args.steps), "algorithmic_flops_per_launch": fl,
+                     "note": "a latency-bound factorisation (64 dependent panel steps at N = 4096): the fraction of the MFMA peak says how far, not how well tuned"},
+        "phases_ms": {"factorisation_each": round(f_ms, 4), "prediction_kernels": round(p_ms, 4)},
+        "exp_rate": round(float(M) * N / (p_ms * 1e-3), 1) if p_ms > 0 else None,
+        "nlml": {"value": val.value, "gradient": [float(g) for g in grad]},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding
+        ora = binding.load()
+        t0 = time.perf_counter()
+        ora.nlml(x, X, y)
+        t_val = time.perf_counter() - t0
+        # the prediction re-factors K (as the reference's predict_phase does) and then costs M N exponentials: two sample sizes separate the two parts
+        m1, m2 = 1024, 4096
+        t0 = time.perf_counter()
+        ora.nlml_predict(x, X, y, grid[:m1])
+        t1 = time.perf_counter()
+        ora.nlml_predict(x, X, y, grid[:m2])
+        t2 = time.perf_counter()
+        per_point = max(0.0, ((t2 - t1) - (t1 - t0)) / (m2 - m1))
+        fixed = max(0.0, (t1 - t0) - per_point * m1)
+        t_pred = fixed + per_point * M
+        result["cpu_baseline"] = {"value": round(1e3 * (t_val + t_pred), 1), "unit": "ms/step", "cores": ora.num_threads, "kind": "port", "cpu_model": cpu_model(),
+                                  "sample": f"oracle (CPU restatement, OpenMP, {ora.num_threads} threads): NLML value + gradient once ({t_val:.2f} s) + prediction: its "
+                                            f"factorisation ({fixed:.2f} s) + {per_point * 1e6:.2f} us per grid point from samples of {m1} and {m2} points, scaled to M = {M} ({t_pred:.2f} s); one run"}
     if rank == 0:
         emit(result)
     api.close()

@@ -2495,19 +2495,22 @@ extern "C"
 	}
 
 	// ---- negative_log_marginal_likelihood / predict_phase (test/gpr.cpp:499-532, 654-706) -------------------------------
-	// shared: Gram, Cholesky, inverse factor, b = K^-1 y (labels are NOT rescaled on this path)
+	// shared: Gram, Cholesky, inverse factor, b = K^-1 y (labels are NOT rescaled on this path).  Enqueue only; `info` (device, one double's
+	// slot) receives the factorisation's info word and a negative one turns b into NaN (colpass_kernel), so that nothing derived from an
+	// unfinished factor looks like a number; the callers read the word back with their results and repeat the call with one launch per panel.
 	static int nlml_solve(gple_ctx* ctx, const double x[5], const double* X, const double* y, size_t N, Scratch& Xt, Scratch& yd, Scratch& T,
-		Scratch& bvec, int* n_out)
+		Scratch& bvec, Scratch& info, int* n_out)
 	{
 		hipStream_t st = ctx->stream;
 		const int n = static_cast<int>(round_up(N, NPAD));
 		*n_out = n;
-		Scratch L(ctx), part(ctx), u(ctx), w(ctx), info(ctx);
+		Scratch L(ctx), work(ctx), part(ctx), u(ctx), w(ctx);
 		GPLE_HIP(ctx, Xt.get(2 * static_cast<size_t>(n)));
 		GPLE_HIP(ctx, yd.get(n));
 		GPLE_HIP(ctx, T.get(static_cast<size_t>(n) * n));
 		GPLE_HIP(ctx, bvec.get(n));
 		GPLE_HIP(ctx, L.get(static_cast<size_t>(n) * n));
+		GPLE_HIP(ctx, work.get(chol_inverse_work_doubles(n)));
 		GPLE_HIP(ctx, part.get(static_cast<size_t>(n / 256) * n));
 		GPLE_HIP(ctx, u.get(n));
 		GPLE_HIP(ctx, w.get(n));
@@ -2515,35 +2518,35 @@ extern "C"
 		GPLE_HIP(ctx, hipMemsetAsync(Xt.p, 0, 2 * static_cast<size_t>(n) * 8, st));
 		GPLE_HIP(ctx, hipMemsetAsync(yd.p, 0, static_cast<size_t>(n) * 8, st));
 		GPLE_HIP(ctx, hipMemsetAsync(info.p, 0, 8, st));
+		// (unlike a fit's, this T is cleared: trmv_lower below walks whole 256-column chunks of a row, the blocks above the diagonal 64-blocks
+		// included — a fit gets u = L^-1 y from the label row of its factorisation instead; 30 us at n = 4096)
 		GPLE_HIP(ctx, hipMemsetAsync(T.p, 0, static_cast<size_t>(n) * n * 8, st));
 		GPLE_HIP(ctx, copy_in(st, Xt.p, X, 2 * N, false));
 		GPLE_HIP(ctx, copy_in(st, yd.p, y, N, false));
-		// the factorisation's info word is looked at before anything is derived from T (this path synchronises anyway, small N): a give-up of
-		// the one-launch scheme (info = -1) is repeated with one launch per panel, as in recover_fit
-		for (int attempt = 0;; ++attempt)
-		{
-			CholSchemeScope scheme(attempt == 0 ? ctx->chol_scheme : 0);
-			Scratch work(ctx); // sized for the scheme in force
-			GPLE_HIP(ctx, work.get(chol_inverse_work_doubles(n)));
-			GPLE_HIP(ctx, hipMemsetAsync(info.p, 0, 8, st));
-			GPLE_HIP(ctx, launch_nlml_gram(st, Xt.p, static_cast<int>(N), n, x, L.p));
-			GPLE_HIP(ctx, chol_inverse_factor(ctx, st, L.p, n, n, T.p, n, reinterpret_cast<int*>(info.p), work.p));
-			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_NLML + 8, info.p, 8, hipMemcpyDeviceToHost, st));
-			GPLE_HIP(ctx, hipStreamSynchronize(st));
-			int info_i;
-			std::memcpy(&info_i, ctx->host_scalars + HS_NLML + 8, sizeof(int));
-			if (info_i >= 0) break;
-			ctx->dag_giveups += 1;
-			if (attempt == 1)
-			{
-				std::lock_guard<std::mutex> lk(ctx->mu);
-				ctx->last_error = "the factorisation gave up waiting (info = -1) and so did its repetition with one launch per panel";
-				return GPLE_ERR_TIMEOUT;
-			}
-			ctx->dag_recoveries += 1;
-		}
+		GPLE_HIP(ctx, launch_nlml_gram(st, Xt.p, static_cast<int>(N), n, x, L.p));
+		timer_start(ctx, GPLE_TIMER_FIT); // the factorisation + inverse factor: what the NLML workloads of bench.py price against the fp64 MFMA peak
+		GPLE_HIP(ctx, chol_inverse_factor(ctx, st, L.p, n, n, T.p, n, reinterpret_cast<int*>(info.p), work.p));
+		timer_stop(ctx, GPLE_TIMER_FIT);
 		GPLE_HIP(ctx, launch_trmv_lower(st, T.p, n, n, yd.p, part.p, u.p));
-		GPLE_HIP(ctx, launch_colpass(st, T.p, n, n, u.p, bvec.p, w.p, 0, nullptr));
+		GPLE_HIP(ctx, launch_colpass(st, T.p, n, n, u.p, bvec.p, w.p, 0, nullptr, reinterpret_cast<int*>(info.p)));
+		return GPLE_OK;
+	}
+	// after the caller's synchronisation: did the factorisation of this attempt give up?  (the word was copied to host_scalars[HS_NLML + 8])
+	static int nlml_gave_up(gple_ctx* ctx, int attempt, bool* again)
+	{
+		int info_i;
+		std::memcpy(&info_i, ctx->host_scalars + HS_NLML + 8, sizeof(int));
+		*again = false;
+		if (info_i >= 0) return GPLE_OK;
+		ctx->dag_giveups += 1;
+		if (attempt == 1)
+		{
+			std::lock_guard<std::mutex> lk(ctx->mu);
+			ctx->last_error = "the factorisation gave up waiting (info = -1) and so did its repetition with one launch per panel";
+			return GPLE_ERR_TIMEOUT;
+		}
+		ctx->dag_recoveries += 1;
+		*again = true;
 		return GPLE_OK;
 	}
 
@@ -2563,21 +2566,30 @@ extern "C"
 		hipStream_t st = ctx->stream;
 		double x5[5];
 		nlml_params(x, n, x5);
-		Scratch Xt(ctx), yd(ctx), T(ctx), b(ctx), out(ctx), W(ctx), part(ctx);
-		int np = 0;
-		GPLE_TRY(nlml_solve(ctx, x5, X, y, N, Xt, yd, T, b, &np));
-		GPLE_HIP(ctx, out.get(8));
-		GPLE_HIP(ctx, launch_nlml_value(st, T.p, np, yd.p, b.p, static_cast<int>(N), out.p));
-		if (grad)
+		for (int attempt = 0;; ++attempt)
 		{
-			const size_t g = (N + 63) / 64;
-			GPLE_HIP(ctx, W.get(static_cast<size_t>(np) * np));
-			GPLE_HIP(ctx, part.get(5 * g * g));
-			GPLE_HIP(ctx, lauum_full(st, T.p, np, W.p, np, np));
-			GPLE_HIP(ctx, launch_nlml_grad(st, Xt.p, static_cast<int>(N), W.p, np, b.p, x5, part.p, out.p + 1));
+			CholSchemeScope scheme(attempt == 0 ? ctx->chol_scheme : 0); // second attempt: one launch per panel (a give-up of the one-launch scheme)
+			Scratch Xt(ctx), yd(ctx), T(ctx), b(ctx), out(ctx), W(ctx), part(ctx), info(ctx);
+			int np = 0;
+			GPLE_TRY(nlml_solve(ctx, x5, X, y, N, Xt, yd, T, b, info, &np));
+			GPLE_HIP(ctx, out.get(8));
+			GPLE_HIP(ctx, launch_nlml_value(st, T.p, np, yd.p, b.p, static_cast<int>(N), out.p));
+			if (grad)
+			{
+				const size_t g = (N + 63) / 64;
+				GPLE_HIP(ctx, W.get(static_cast<size_t>(np) * np));
+				GPLE_HIP(ctx, part.get(5 * g * g));
+				GPLE_HIP(ctx, lauum_full(st, T.p, np, W.p, np, np));
+				GPLE_HIP(ctx, launch_nlml_grad(st, Xt.p, static_cast<int>(N), W.p, np, b.p, x5, part.p, out.p + 1));
+			}
+			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_NLML, out.p, 6 * 8, hipMemcpyDeviceToHost, st));
+			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_NLML + 8, info.p, 8, hipMemcpyDeviceToHost, st));
+			GPLE_HIP(ctx, hipStreamSynchronize(st));
+			timer_collect(ctx);
+			bool again;
+			GPLE_TRY(nlml_gave_up(ctx, attempt, &again));
+			if (!again) break;
 		}
-		GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_NLML, out.p, 6 * 8, hipMemcpyDeviceToHost, st));
-		GPLE_HIP(ctx, hipStreamSynchronize(st));
 		*value = ctx->host_scalars[HS_NLML];
 		if (grad)
 		{
@@ -2601,21 +2613,33 @@ extern "C"
 		const bool dev = flags & GPLE_IO_DEVICE; // applies to Xs / mean only; the training set is small and host-side
 		double x5[5];
 		nlml_params(x, n, x5);
-		Scratch Xt(ctx), yd(ctx), T(ctx), b(ctx), xs(ctx), o(ctx);
-		int np = 0;
-		GPLE_TRY(nlml_solve(ctx, x5, X, y, N, Xt, yd, T, b, &np));
-		const double* xs_dev = Xs;
-		double* o_dev = mean;
-		if (!dev)
+		for (int attempt = 0;; ++attempt)
 		{
-			GPLE_HIP(ctx, xs.get(2 * M));
-			GPLE_HIP(ctx, o.get(M));
-			GPLE_HIP(ctx, copy_in(st, xs.p, Xs, 2 * M, false));
-			xs_dev = xs.p, o_dev = o.p;
+			CholSchemeScope scheme(attempt == 0 ? ctx->chol_scheme : 0);
+			Scratch Xt(ctx), yd(ctx), T(ctx), b(ctx), xs(ctx), o(ctx), part(ctx), info(ctx);
+			int np = 0;
+			GPLE_TRY(nlml_solve(ctx, x5, X, y, N, Xt, yd, T, b, info, &np));
+			const double* xs_dev = Xs;
+			double* o_dev = mean;
+			if (!dev)
+			{
+				GPLE_HIP(ctx, xs.get(2 * M));
+				GPLE_HIP(ctx, o.get(M));
+				GPLE_HIP(ctx, copy_in(st, xs.p, Xs, 2 * M, false));
+				xs_dev = xs.p, o_dev = o.p;
+			}
+			GPLE_HIP(ctx, part.get(static_cast<size_t>(nlml_predict_ksplit(static_cast<int>(M), static_cast<int>(N))) * M));
+			timer_start(ctx, GPLE_TIMER_PREDICT);
+			GPLE_HIP(ctx, launch_nlml_predict(st, xs_dev, static_cast<int>(M), Xt.p, static_cast<int>(N), b.p, x5, part.p, o_dev));
+			timer_stop(ctx, GPLE_TIMER_PREDICT);
+			if (!dev) GPLE_HIP(ctx, copy_out(st, mean, o.p, M, false));
+			GPLE_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + HS_NLML + 8, info.p, 8, hipMemcpyDeviceToHost, st));
+			GPLE_HIP(ctx, hipStreamSynchronize(st));
+			timer_collect(ctx);
+			bool again;
+			GPLE_TRY(nlml_gave_up(ctx, attempt, &again));
+			if (!again) break;
 		}
-		GPLE_HIP(ctx, launch_nlml_predict(st, xs_dev, static_cast<int>(M), Xt.p, static_cast<int>(N), b.p, x5, o_dev));
-		if (!dev) GPLE_HIP(ctx, copy_out(st, mean, o.p, M, false));
-		GPLE_HIP(ctx, hipStreamSynchronize(st));
 		return GPLE_OK;
 	}
 

@@ -20,6 +20,31 @@ namespace gple
 		SEParam p[3];
 	};
 
+	// exp(x) for finite x <= 0 (the argument of a squared-exponential kernel), fp64, < 1 ulp:
+	// x = k ln2 + r (Cody-Waite with an FMA), |r| <= ln2/2, degree-12 Taylor/Horner, scaling by v_ldexp_f64 (which
+	// handles the gradual underflow for x < -708).  No special-case branches.
+	__device__ __forceinline__ double exp_nonpos(double x)
+	{
+		x = fmax(x, -1100.0); // below that the result is 0 anyway; keeps the int conversion in range
+		const double kd = rint(x * 1.4426950408889634074);
+		double r = fma(kd, -6.93147180369123816490e-01, x);
+		r = fma(kd, -1.90821492927058770002e-10, r);
+		double p = 2.08767569878680989792e-09; // 1/12!
+		p = fma(p, r, 2.50521083854417187751e-08);
+		p = fma(p, r, 2.75573192239858906526e-07);
+		p = fma(p, r, 2.75573192239858906526e-06);
+		p = fma(p, r, 2.48015873015873015873e-05);
+		p = fma(p, r, 1.98412698412698412698e-04);
+		p = fma(p, r, 1.38888888888888888889e-03);
+		p = fma(p, r, 8.33333333333333333333e-03);
+		p = fma(p, r, 4.16666666666666666667e-02);
+		p = fma(p, r, 1.66666666666666666667e-01);
+		p = fma(p, r, 0.5);
+		p = fma(p, r, 1.0);
+		p = fma(p, r, 1.0);
+		return ldexp(p, static_cast<int>(kd));
+	}
+
 	// ---- training side ---------------------------------------------------------------------------------------
 	// ys[i] = s * y[i*stride + offset] for i < N (0 for N <= i < Np), s = 10 / max_i |label_i|, written to *s_out.
 	// complex_abs != 0: |label| is the complex modulus of the (re,im) pair and both halves are produced:
@@ -117,7 +142,9 @@ namespace gple
 	hipError_t launch_nlml_value(hipStream_t s, const double* T, long ldt, const double* y, const double* b, int N, double* out);
 	hipError_t launch_nlml_grad(hipStream_t s, const double* Xt, int N, const double* W, long ldw, const double* b, const double x[5], double* part,
 		double* out5);
-	hipError_t launch_nlml_predict(hipStream_t s, const double* Xs, int M, const double* Xt, int N, const double* b, const double x[5], double* mean);
+	// part: nlml_predict_ksplit(M, N) * M doubles of partial sums
+	int nlml_predict_ksplit(int M, int N);
+	hipError_t launch_nlml_predict(hipStream_t s, const double* Xs, int M, const double* Xt, int N, const double* b, const double x[5], double* part, double* mean);
 
 	// ---- step loop around the GP (gple_evolve.hip): Tully models, MQCLE propagation, Metropolis ---------------------------------
 	hipError_t launch_pes(hipStream_t s, const double* x, int M, int model, double* out6);

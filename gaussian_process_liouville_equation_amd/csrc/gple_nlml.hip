@@ -126,17 +126,36 @@ namespace gple
 				if (threadIdx.x == 0) out[ip] = tot / 2.0; // trace / 2, test/gpr.cpp:525
 			}
 		}
-		// mean-only prediction, the noise kernel is left out off the training set (test/gpr.cpp:384-388, 700)
-		__global__ void __launch_bounds__(256) nlml_predict_kernel(const double* __restrict__ Xs, int M, const double* __restrict__ Xt, int N,
-			const double* __restrict__ b, double wg, ArdW w, double* __restrict__ mean)
+		// mean-only prediction, the noise kernel is left out off the training set (test/gpr.cpp:384-388, 700): mean_i = sum_k k(x*_i, x_k) b_k.
+		// One thread per grid point, blockIdx.y selects a k-range (a 256 x 256 grid is only 512 blocks of 128 points: the k-split fills the chip;
+		// round 3's kernel was one thread per point over all N with libm's exp — 4096 dependent exp calls per thread).  The training point and
+		// weight of every k are uniform (scalar) loads; the exponential is the branch-free one of the predict path (argument <= 0, < 1 ulp).
+		// part[ky][i] = the k-range's sum; nlml_predict_sum_kernel adds the ranges in order.
+		__global__ void __launch_bounds__(128) nlml_predict_kernel(const double* __restrict__ Xs, int M, const double* __restrict__ Xt, int N,
+			const double* __restrict__ b, double wg, ArdW w, double* __restrict__ part)
+		{
+			const int i = blockIdx.x * 128 + threadIdx.x;
+			const int ic = i < M ? i : M - 1;
+			const double x0 = Xs[2 * ic], x1 = Xs[2 * ic + 1];
+			const double amp = wg * wg;
+			const int kper = (N + gridDim.y - 1) / gridDim.y, kbeg = blockIdx.y * kper, kend = kbeg + kper < N ? kbeg + kper : N;
+			double acc = 0.0;
+			for (int k = kbeg; k < kend; ++k)
+			{
+				const double e0 = __dsub_rn(x0, Xt[2 * k]), e1 = __dsub_rn(x1, Xt[2 * k + 1]);
+				const double d0 = __dadd_rn(__dmul_rn(w.a, e0), __dmul_rn(w.c, e1)), d1 = __dmul_rn(w.b, e1);
+				const double g = exp_nonpos(__dmul_rn(-0.5, fma(d0, d0, __dmul_rn(d1, d1))));
+				acc = fma(__dmul_rn(amp, g), b[k], acc);
+			}
+			if (i < M) part[static_cast<long>(blockIdx.y) * M + i] = acc;
+		}
+		__global__ void __launch_bounds__(256) nlml_predict_sum_kernel(const double* __restrict__ part, int M, int ksplit, double* __restrict__ mean)
 		{
 			const int i = blockIdx.x * 256 + threadIdx.x;
 			if (i >= M) return;
-			const double x0 = Xs[2 * i], x1 = Xs[2 * i + 1];
-			const double amp = wg * wg;
-			double acc = 0.0;
-			for (int k = 0; k < N; ++k) acc += __dmul_rn(amp, ard(x0, x1, Xt[2 * k], Xt[2 * k + 1], w)) * b[k];
-			mean[i] = acc;
+			double s = 0.0;
+			for (int ky = 0; ky < ksplit; ++ky) s += part[static_cast<long>(ky) * M + i];
+			mean[i] = s;
 		}
 	} // namespace
 
@@ -158,10 +177,19 @@ namespace gple
 		hipLaunchKernelGGL(nlml_grad_sum_kernel, dim3(1), dim3(256), 0, s, part, g * g, out5);
 		return hipGetLastError();
 	}
-	hipError_t launch_nlml_predict(hipStream_t s, const double* Xs, int M, const double* Xt, int N, const double* b, const double x[5], double* mean)
+	int nlml_predict_ksplit(int M, int N)
+	{
+		const long blocks = (M + 127) / 128;
+		int ks = 1;
+		while (ks < 64 && blocks * ks < 1024 && N / (2 * ks) >= 64) ks *= 2; // >= 1024 workgroups where the k-ranges stay >= 64 long
+		return ks;
+	}
+	hipError_t launch_nlml_predict(hipStream_t s, const double* Xs, int M, const double* Xt, int N, const double* b, const double x[5], double* part, double* mean)
 	{
 		if (M == 0) return hipSuccess;
-		hipLaunchKernelGGL(nlml_predict_kernel, dim3((M + 255) / 256), dim3(256), 0, s, Xs, M, Xt, N, b, x[1], (ArdW{x[2], x[3], x[4]}), mean);
+		const int ks = nlml_predict_ksplit(M, N);
+		hipLaunchKernelGGL(nlml_predict_kernel, dim3((M + 127) / 128, ks), dim3(128), 0, s, Xs, M, Xt, N, b, x[1], (ArdW{x[2], x[3], x[4]}), part);
+		hipLaunchKernelGGL(nlml_predict_sum_kernel, dim3((M + 255) / 256), dim3(256), 0, s, part, M, ks, mean);
 		return hipGetLastError();
 	}
 } // namespace gple

@@ -50,31 +50,6 @@ namespace gple
 			return ks;
 		}
 
-		// exp(x) for finite x <= 0 (the argument of a squared-exponential kernel), fp64, < 1 ulp:
-		// x = k ln2 + r (Cody-Waite with an FMA), |r| <= ln2/2, degree-12 Taylor/Horner, scaling by v_ldexp_f64 (which
-		// handles the gradual underflow for x < -708).  No special-case branches.
-		__device__ __forceinline__ double exp_nonpos(double x)
-		{
-			x = fmax(x, -1100.0); // below that the result is 0 anyway; keeps the int conversion in range
-			const double kd = rint(x * 1.4426950408889634074);
-			double r = fma(kd, -6.93147180369123816490e-01, x);
-			r = fma(kd, -1.90821492927058770002e-10, r);
-			double p = 2.08767569878680989792e-09; // 1/12!
-			p = fma(p, r, 2.50521083854417187751e-08);
-			p = fma(p, r, 2.75573192239858906526e-07);
-			p = fma(p, r, 2.75573192239858906526e-06);
-			p = fma(p, r, 2.48015873015873015873e-05);
-			p = fma(p, r, 1.98412698412698412698e-04);
-			p = fma(p, r, 1.38888888888888888889e-03);
-			p = fma(p, r, 8.33333333333333333333e-03);
-			p = fma(p, r, 4.16666666666666666667e-02);
-			p = fma(p, r, 1.66666666666666666667e-01);
-			p = fma(p, r, 0.5);
-			p = fma(p, r, 1.0);
-			p = fma(p, r, 1.0);
-			return ldexp(p, static_cast<int>(kd));
-		}
-
 		// K*(row, k) = amp (exp(-((dx rl0)^2 + (dp rl1)^2)/2) + n2 [x* == x_k])  for the rows [row0, row0 + rows) of the
 		// typed test set -> Ks (column-major, ld = rows); partial means mu_part[ky][row] = sum_{k in range ky} K* v[k].
 		// One thread per row, blockIdx.y selects the k-range; the training point of each k is a scalar load.

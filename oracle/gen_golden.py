@@ -151,7 +151,8 @@ def real_case(seed, N, M, theta, Mv, coincident):
     v = W * ys
     out = dict(theta=np.array(theta), X=X, y=y, Xs=Xs, Xv=Xv, tv=tv)
     out.update(K=tonp(K), dK=np.stack([tonp(d) for d in dK]), W=tonp(W), v=tonp(v), rescale=float(s))
-    out["cond"] = float(mp.norm(K, 2) * mp.norm(W, 2)) if N <= 40 else np.nan
+    # (2-norm condition: in mpmath for the small cases; for the large ones numpy's on the rounded matrix — it only scales tolerances)
+    out["cond"] = float(mp.norm(K, 2) * mp.norm(W, 2)) if N <= 40 else float(np.linalg.cond(tonp(K)))
     out["magnitude"] = float(mp.sqrt(abs((ys.T * v)[0, 0] / N)))  # kernel.h:167-179
     diagW = [W[i, i] for i in range(N)]
     out["error"] = float(mp.fsum([(v[i] / diagW[i]) ** 2 for i in range(N)]))  # :285
@@ -203,6 +204,8 @@ def real_case(seed, N, M, theta, Mv, coincident):
     out.update({"t_" + k: val for k, val in pt.items()})
     pv = predict(Xv, tv)
     out.update({"v_" + k: val for k, val in pv.items()})
+    if N > 64:  # the large case pins what crosses tile boundaries (factor, inverse, weights, predictions, derivative members); its 4 N x N
+        out.pop("dK")  # derivative Grams are entry-wise formulas already pinned by the small cases
     return out
 
 
@@ -372,12 +375,19 @@ REAL_CASES = {
     "real_a": (20240607, 24, 40, (1.3, 0.8, 0.6, 0.05), 30, 3),
     "real_b": (20240608, 32, 48, (1.0, 0.7086, 0.7056, 0.01), 40, 0),  # the reference's initial parameters (opt.cpp:25-27)
     "real_c": (20240609, 8, 16, (0.7, 0.3, 1.1, 0.2), 8, 1),
+    # beyond one 64-block (SURVEY.md §8c planned N up to 64, M up to 256): N = 136 pads to n = 256 = four panels of the factorisation, three
+    # of them with real rows, so the multi-panel factorisation, the in-launch inverse and the trailing updates meet 50-digit values directly;
+    # M = 256 fills two 128-row blocks of the contraction
+    "real_d": (20240610, 136, 256, (1.0, 0.7086, 0.7056, 0.02), 64, 4),
 }
 COMPLEX_CASES = {
     # theta = (s, sR, lRx, lRp, sI, lIx, lIp, sn)
     "complex_a": (20240617, 12, 20, (1.0, 1.2, 0.8, 0.6, 0.9, 0.7, 0.9, 0.05), 12, 2),
     "complex_b": (20240618, 16, 24, (1.0, 1.0, 0.7086, 0.7056, 1.0, 0.7086, 0.7056, 0.01), 16, 0),  # opt.cpp:306-332
     "complex_c": (20240619, 8, 12, (1.4, 0.8, 0.5, 0.9, 1.1, 0.8, 0.4, 0.1), 8, 1),  # s != 1 pins the missing-s^2 quirks
+    # N = 72: 144 real rows in the [Re; Im] embedding (Re rows 0..71 of block rows 0-1, Im rows 256..327 of block rows 4-5 at n = 512): more
+    # than two 64-blocks of real data, the Re-Im coupling blocks span panels
+    "complex_d": (20240620, 72, 96, (1.0, 1.2, 0.8, 0.6, 0.9, 0.7, 0.9, 0.05), 32, 2),
 }
 
 if __name__ == "__main__":

@@ -19,14 +19,23 @@ def cond_tol(g, factor=200.0, floor=1e-12):
     return max(floor, factor * cond * EPS)
 
 
-def check_gram_ulp(K, Kref, theta, X, XR=None):
-    """|K - Kref| <= (4 + |a|) eps |Kref| with a the exponent argument."""
+def check_gram_ulp(K, Kref, theta, X, XR=None, proven=False):
+    """|K - Kref| <= (4 + |a|) 2 u |Kref| with a the exponent argument, u = 2^-53: SURVEY.md §8(d)'s model of a Gram entry's rounding.
+    proven=True (the fixtures with 10^4 entries and more): the worst case of the reference's operation order instead — subtract, divide by l,
+    square, add, negate, halve, exp, add the ridge, multiply by sf^2 (kernel.cpp:46-47, 227): the argument carries at most 6 u relative
+    (two roundings in d, five in d^2, one more in the sum), the exponential turns that into 6 |a| u, exp itself (< 1 ulp), the addition
+    and the product add 4 u: (4 + 6 |a|) u.  The model above is what a typical entry keeps to — 4 of the 18 496 entries of real_d exceed it, by
+    up to 18 %, with the CPU oracle (glibc exp) as well as on the GPU — the proven bound is what no correct implementation may exceed."""
     XR = X if XR is None else XR
     d0 = (X[:, None, 0] - XR[None, :, 0]) / theta[1]
     d1 = (X[:, None, 1] - XR[None, :, 1]) / theta[2]
     a = 0.5 * (d0 ** 2 + d1 ** 2)
-    bound = (4.0 + a) * 2 * EPS * np.abs(Kref) + 1e-300
+    factor = np.maximum((4.0 + a) * 2, 4.0 + 6.0 * a) if proven else (4.0 + a) * 2
+    bound = factor * EPS * np.abs(Kref) + 1e-300
     assert np.all(np.abs(K - Kref) <= bound), float((np.abs(K - Kref) / bound).max())
+    if proven:  # ... and all but a handful of entries keep to the model
+        model = (4.0 + a) * 2 * EPS * np.abs(Kref) + 1e-300
+        assert (np.abs(K - Kref) > model).mean() <= 1e-3, float((np.abs(K - Kref) > model).mean())
 
 
 def check_real_case(api, g, deriv, tight=None):
@@ -39,7 +48,7 @@ def check_real_case(api, g, deriv, tight=None):
     for k in ("magnitude", "error", "population", "purity"):
         assert abs(s[k] - g[k]) <= tol * abs(g[k]), (k, s[k], float(g[k]))
     assert rel(s["first_order_average"], g["first_order"]) <= tol
-    check_gram_ulp(fit.get(c.R_KERNEL), g["K"], g["theta"], g["X"])
+    check_gram_ulp(fit.get(c.R_KERNEL), g["K"], g["theta"], g["X"], proven=g["K"].size > 10000)
     assert rel(fit.get(c.R_INVERSE), g["W"]) <= tol
     assert rel(fit.get(c.R_INVERSE_DIAG), np.diag(g["W"])) <= tol
     assert rel(fit.get(c.R_INVLBL), g["v"]) <= tol
@@ -93,6 +102,10 @@ def check_complex_case(api, g, deriv, tol):
 # fixtures: (name, relative tolerance for the complex cases — cond is not stored there)
 REAL_FIXTURES = ["real_a", "real_b", "real_c"]
 COMPLEX_FIXTURES = [("complex_a", 1e-10), ("complex_b", 1e-7), ("complex_c", 1e-11)]
+# beyond one 64-block of the factorisation / one 128-row block of the contraction (oracle/gen_golden.py: real N = 136, M = 256; complex N = 72,
+# i.e. 144 real rows): the multi-panel factorisation, the in-launch inverse and the contraction's tiling against 50-digit values directly
+REAL_FIXTURES_LARGE = ["real_d"]
+COMPLEX_FIXTURES_LARGE = [("complex_d", 6e-10)]  # 200 cond(K) eps with cond(K) = 2.6e4, the rule of the real cases (the oracle is at 1e-12)
 
 
 def synthetic_real(N, M, seed):

@@ -105,13 +105,37 @@ def check_complex_fit_and_rows(gpu, fit, theta, X, grid, p, rows):
     k, kt = complex_rect_kernels(theta, grid[rows], X)
     mu = k @ v + kt @ v.conj()
     kss = theta[0] ** 2 * (theta[1] ** 2 + theta[4] ** 2 + theta[7] ** 2)
-    var = (kss - np.einsum("ij,jk,ik->i", k, P, k) - np.einsum("ij,jk,ik->i", kt, P.conj(), kt.conj())
-           - np.einsum("ij,jk,ik->i", kt, Q, k) - np.einsum("ij,jk,ik->i", k, Q.conj(), kt.conj())).real
+
+    def reference_form(idx, real, cplx):  # var_i = Re[k** - k P k^T - k~ conj(P) k~^H - k~ Q k^T - k conj(Q) k~^H], row by row
+        Pw, Qw = P.astype(cplx), Q.astype(cplx)
+        out = []
+        for i in idx:
+            kr, pr = k[i].astype(real), kt[i].astype(cplx)
+            t = (kr @ (Pw @ kr)) + (pr @ (Pw.conj() @ pr.conj())) + (pr @ (Qw @ kr)) + (kr @ (Qw.conj() @ pr.conj()))
+            out.append(real(kss) - t.real)
+        return np.array(out, dtype=np.float64)
+
     # numpy's own rounding of these cancelling sums is ~ eps * sum |k| |v| (cond(K) ~ N / sn^2): part of the tolerance
     round_off = 100 * parity.EPS * ((np.abs(k) + np.abs(kt)) @ np.abs(v)).max()
     assert np.abs(mu - p["prediction"][rows]).max() <= 1e-8 * np.abs(p["prediction"]).max() + round_off
-    # the reference's form cancels four N^2 sums of size ~cond(K) ~ N / sn^2 in numpy's own rounding: the tolerance grows with N
-    assert np.abs(var - p["variance"][rows]).max() <= 1e-6 * max(1.0, N / 4096.0)
+    # The variance.  The reference's form cancels four N^2 sums of size ~ cond(K) ~ N / sn^2; the library's is k** - |T k*|^2, a sum of squares.
+    # Which side is off when they differ?  Round 3 widened this comparison with N after C5c missed 1e-6 by 17 %; round 4 measured it
+    # (probes/r04_variance_forms.py, 8 rows nearest the packet, N = 2048 / 4096 / 8192): the reference form evaluated in extended precision
+    # (x87 long double, 11 more mantissa bits, from the same P, Q) lies 4.8e-9 / 8.2e-9 / 2.3e-8 from the library's value, and numpy's fp64
+    # evaluation of the same form lies 1.1e-8 / 3.4e-8 / 7.1e-8 from its own extended-precision value: the fp64 evaluation of the reference
+    # form is the noisier side, and what is left between the library and the extended evaluation is the conditioning of P and Q themselves
+    # (they are fp64 results: relative error ~ cond(K) eps, cond(K) ~ N / sn^2).  So: (1) the library against the extended-precision form on
+    # 8 rows, at 4 cond eps k**; (2) the fp64 form on all rows, at ITS OWN measured distance from the extended form plus the same bound.
+    sub = list(range(0, len(rows), max(1, len(rows) // 8)))[:8]
+    v_ext = reference_form(sub, np.longdouble, np.clongdouble)
+    v_f64 = reference_form(range(len(rows)), np.float64, np.complex128)
+    cond_bound = 4.0 * (N / theta[7] ** 2) * parity.EPS * kss
+    hip = p["variance"][rows]
+    assert np.abs(hip[sub] - v_ext).max() <= cond_bound, (np.abs(hip[sub] - v_ext).max(), cond_bound)
+    own = np.abs(v_f64[sub] - v_ext).max()  # the fp64 form's own rounding, measured on the rows that have an extended-precision value
+    print(f"N = {N}: |HIP - extended form| = {np.abs(hip[sub] - v_ext).max():.2e} (bound {cond_bound:.2e}), |fp64 form - extended form| = {own:.2e}, "
+          f"|HIP - fp64 form| = {np.abs(hip - v_f64).max():.2e}")
+    assert np.abs(hip - v_f64).max() <= 4.0 * own + cond_bound, (np.abs(hip - v_f64).max(), own, cond_bound)
     return kss
 
 

@@ -12,12 +12,12 @@ from tests.conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", parity.REAL_FIXTURES)
+@pytest.mark.parametrize("name", parity.REAL_FIXTURES + parity.REAL_FIXTURES_LARGE)
 def test_real_fixture(gpu, name):
     parity.check_real_case(gpu, load_golden(name), deriv=True)
 
 
-@pytest.mark.parametrize("name,tol", parity.COMPLEX_FIXTURES)
+@pytest.mark.parametrize("name,tol", parity.COMPLEX_FIXTURES + parity.COMPLEX_FIXTURES_LARGE)
 def test_complex_fixture(gpu, name, tol):
     parity.check_complex_case(gpu, load_golden(name), deriv=True, tol=tol)
 
@@ -226,6 +226,51 @@ def test_nlml_value_gradient_and_prediction(gpu, oracle):
     assert abs(vg - ref) <= 1e-9 * abs(ref)
     mg, mo = gpu.nlml_predict(x, X, y, Xs), oracle.nlml_predict(x, X, y, Xs)
     assert np.abs(mg - mo).max() <= 1e-9 * np.abs(mo).max()
+
+
+@pytest.mark.parametrize("N", [1024, 4096])
+def test_nlml_at_baseline_sizes(gpu, oracle, N):
+    """negative_log_marginal_likelihood + predict_phase (test/gpr.cpp:499-532, 654-706) at the N of BASELINE configs[1] / configs[3] (the
+    reference runs them at N = 200): the value against numpy's Cholesky, the gradient against central differences of the value (ARD weights:
+    true derivatives; the two kernel weights: HALF of it — the reference pushes w K instead of 2 w K, test/gpr.cpp:425,432), the mean-only
+    prediction on a 256 x 256 grid against the oracle on 64 of its rows and against numpy on 8."""
+    X, y, _ = parity.synthetic_real(N, 4, 4400 + N)
+    x = np.array([0.05, 1.3, 1.0 / 0.7086, 1.0 / 0.7056])  # (w_d, w_g, a_x, a_p): noise 0.05, ARD weights = inverse lengths (test/gpr.cpp:167-173)
+
+    def gram(xx, A, B):
+        d0, d1 = xx[2] * (A[:, None, 0] - B[None, :, 0]), xx[3] * (A[:, None, 1] - B[None, :, 1])
+        return xx[1] ** 2 * np.exp(-0.5 * (d0 ** 2 + d1 ** 2))
+
+    def f(xx):
+        Kn = gram(xx, X, X) + xx[0] ** 2 * np.eye(N)
+        L = np.linalg.cholesky(Kn)
+        z = np.linalg.solve(L, y)
+        return 0.5 * z @ z + np.log(np.diag(L)).sum()
+
+    val, grad = gpu.nlml(x, X, y)
+    ref = f(x)
+    cond = np.linalg.cond(gram(x, X, X) + x[0] ** 2 * np.eye(N))
+    assert abs(val - ref) <= 50 * cond * parity.EPS * abs(ref) + 1e-9 * abs(ref), (val, ref, cond)
+    assert gpu.nlml(x, X, y, want_grad=False)[0] == val  # value alone: the same bits
+    for ip in range(4):
+        h = 1e-5 * x[ip]
+        xp, xm = x.copy(), x.copy()
+        xp[ip] += h
+        xm[ip] -= h
+        fd = (f(xp) - f(xm)) / (2 * h)
+        expect = fd / 2 if ip < 2 else fd
+        assert abs(grad[ip] - expect) <= 2e-5 * max(1.0, abs(expect)), (ip, grad[ip], expect)
+    G = 256
+    gx, gp = np.meshgrid(np.linspace(-13.0, -7.0, G), np.linspace(11.0, 17.0, G), indexing="ij")
+    grid = np.ascontiguousarray(np.stack([gx.ravel(), gp.ravel()], axis=1))
+    mean = gpu.nlml_predict(x, X, y, grid)
+    assert mean.shape == (G * G,) and np.all(np.isfinite(mean))
+    rows = np.arange(0, G * G, G * G // 64)[:64]
+    mo = oracle.nlml_predict(x, X, y, grid[rows])
+    scale = np.abs(mean).max()
+    assert np.abs(mean[rows] - mo).max() <= 50 * cond * parity.EPS * scale + 1e-9 * scale, np.abs(mean[rows] - mo).max() / scale
+    b = np.linalg.solve(gram(x, X, X) + x[0] ** 2 * np.eye(N), y)
+    assert np.abs(mean[rows[:8]] - gram(x, grid[rows[:8]], X) @ b).max() <= 50 * cond * parity.EPS * scale + 1e-9 * scale
 
 
 def test_nlml_cross_term_ard_against_oracle(gpu, oracle):

@@ -8,12 +8,12 @@ from tests import parity
 from tests.conftest import load_golden
 
 
-@pytest.mark.parametrize("name", parity.REAL_FIXTURES)
+@pytest.mark.parametrize("name", parity.REAL_FIXTURES + parity.REAL_FIXTURES_LARGE)
 def test_real_fixture(oracle, name):
     parity.check_real_case(oracle, load_golden(name), deriv=True)
 
 
-@pytest.mark.parametrize("name,tol", parity.COMPLEX_FIXTURES)
+@pytest.mark.parametrize("name,tol", parity.COMPLEX_FIXTURES + parity.COMPLEX_FIXTURES_LARGE)
 def test_complex_fixture(oracle, name, tol):
     parity.check_complex_case(oracle, load_golden(name), deriv=True, tol=tol)
 
