@@ -2710,6 +2710,13 @@ extern "C"
 		if (recoveries) *recoveries = ctx->dag_recoveries;
 		return GPLE_OK;
 	}
+	int gple_debug_predict_knobs(gple_ctx* ctx, int rownorm_pipe)
+	{
+		if (!ctx) return GPLE_ERR_BAD_ARG;
+		std::lock_guard<std::mutex> lk(ctx->call_mu);
+		if (rownorm_pipe >= 0) ctx->rownorm_pipe = rownorm_pipe >= 2 ? -1 : rownorm_pipe;
+		return GPLE_OK;
+	}
 	int gple_debug_chol_layout(int n, int cap, int* bounds, int* nb, int* forks, int* nf, unsigned long long* work_doubles)
 	{
 		if (n <= 0 || n % 64 || !bounds || !nb || !forks || !nf || !work_doubles) return GPLE_ERR_BAD_ARG;

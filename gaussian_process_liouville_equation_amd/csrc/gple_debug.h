@@ -4,7 +4,8 @@
  *   tests/test_gpu_chol_diag.py, probes/step_probe.py -> gple_debug_potrf_step
  *   tests/test_host_logic.py                          -> gple_debug_chol_layout (no device call)
  *   tests/test_gpu_gemm.py                            -> gple_debug_gemm
- *   tests/test_gpu_chol_diag.py                       -> gple_debug_side_stream, gple_debug_chol_knobs (the give-up test) */
+ *   tests/test_gpu_chol_diag.py                       -> gple_debug_side_stream, gple_debug_chol_knobs (the give-up test)
+ *   tests/test_gpu_parity.py                          -> gple_debug_predict_knobs */
 #ifndef GPLE_DEBUG_H
 #define GPLE_DEBUG_H
 #include "../../include/gple.h"
@@ -37,6 +38,10 @@ extern "C"
 	 * wave of the one-launch scheme gives up (0 = the default, 2^21); dag_blocks: workgroups of its launches (0 = one per CU).  giveups / recoveries
 	 * (nullable): how often the host has seen info = -1 on this context / repeated a factorisation with a launch per panel because of it. */
 	int gple_debug_chol_knobs(gple_ctx* ctx, int scheme, int poll_limit, int dag_blocks, long* giveups, long* recoveries);
+	/* Test knob of the predict path on ONE context: which contraction kernel its large predicts run on — 0 = rownorm2_kernel (a barrier-to-barrier
+	 * k-step), 1 = rownormp_kernel (the k-steps of a unit as one pipeline), 2 = back to the environment's (GPLE_ROWNORM_PIPE); negative: unchanged.
+	 * The two must agree bit for bit (tests/test_gpu_parity.py). */
+	int gple_debug_predict_knobs(gple_ctx* ctx, int rownorm_pipe);
 #ifdef __cplusplus
 }
 #endif

@@ -572,6 +572,244 @@ namespace gple
 		}
 
 
+		// ---- the register-blocked contraction as ONE pipeline over all k-steps of a unit ----------------------------------------
+		// rownorm2_kernel's k-step, as hipcc schedules it: ... 16 MFMAs | barrier | 16 MFMAs (the last group, operands already in registers) |
+		// first operand reads of the next step | ~80 scalar instructions of DMA addressing around six LDS-DMA issues | wait for the operands |
+		// MFMAs.  Both waves of a SIMD come out of the barrier together and stay in step, so they reach the scalar stretch together and the
+		// MFMA pipe idles through it and through the LDS latency behind it: ~900 of a step's 8600 cycles at C4r (MFMA pipe busy 89.8 %).
+		// Here the order behind the barrier is pinned (sched_barrier): the next step's first operands are requested FIRST, then the six DMA
+		// issues go out between the MFMAs of the last group, whose operands were read before the barrier — nothing that follows the barrier
+		// waits for anything but the barrier.  The DMA addressing is two SGPR bases per slab and six constant VGPR offsets (saddr form).
+		// A slab is requested TWO steps ahead of its use... no: one step, as before (issued behind the barrier that ends step s - 1, needed
+		// behind the barrier that ends step s) — but the sequence of slabs runs across N-tiles and virtual groups: the first slabs of the next
+		// tile are requested during the last steps of the current one, so a tile no longer starts with an exposed DMA round trip (16 per row
+		// block at n = 4096, 4 of 160 steps' worth at n = 1024); only a unit does.  The tiles of the unit are listed in LDS in the order
+		// (virtual group, tile) they had before; per accumulator the same MFMAs in the same order, the same sums behind them: same bits as
+		// rownorm2_kernel (test_rownorm_variants_agree_bit_for_bit).
+		constexpr int TL_MAX = 256; // N-tiles of a factor (n <= 65536)
+		template <int AF, int BF, int WNI>
+		__device__ __forceinline__ void rownormp_unit(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt, double* lds,
+			const int* tl, int ntl, double* __restrict__ q, long qstride, int m0, int wm)
+		{
+			constexpr int KB = 16, WN = 16 / BF, ASr = BM + 16;
+			constexpr int ASL = KB * ASr, BSL = KB * BS;
+			static_assert(BM * KB / 2 / NTHREADS == 2 && BN * KB / 2 / NTHREADS == 4, "six DMA instructions per wave and slab");
+			double* const As = lds;
+			double* const Bs = lds + 2 * ASL;
+			double* const red = Bs + 2 * BSL;
+			const int t = threadIdx.x, lane = t & 63;
+			const int fk = lane >> 4, fr = lane & 15;
+			const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+			auto lds_addr = [](const double* p) { return static_cast<unsigned>(reinterpret_cast<unsigned long>((__attribute__((address_space(3))) const double*)p)); };
+			// one LDS-DMA wave instruction: 1 KB from (base + voff) to LDS byte address ldst + poff.  M0 is written, never restored: nothing else in
+			// this kernel reads it (hipcc treats M0 as reserved and sets it in front of each of its own uses; checked on the disassembly)
+			auto dma = [](const double* base, unsigned voff, unsigned ldst, unsigned poff) {
+				asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3" ::"v"(voff), "s"(ldst), "s"(poff), "s"(base) : "memory", "scc");
+			};
+			// wave w fills k-rows w and w + 8 of the K* slab and, of the T slab, half (w & 1) of the k-rows (w >> 1) + 4 qq
+			unsigned voff[6], ldst[6];
+			voff[0] = 16u * lane, voff[1] = voff[0] + 64u * static_cast<unsigned>(rows);
+			ldst[0] = lds_addr(As) + 8u * static_cast<unsigned>(w * ASr), ldst[1] = ldst[0] + 8u * (8 * ASr);
+#pragma unroll
+			for (int qq = 0; qq < 4; ++qq)
+			{
+				voff[2 + qq] = voff[0] + 32u * static_cast<unsigned>(ldt) * qq;
+				ldst[2 + qq] = lds_addr(Bs) + 8u * static_cast<unsigned>(((w >> 1) + 4 * qq) * BS + 128 * (w & 1));
+			}
+			const double* const KsW = Ks + m0 + static_cast<long>(w) * rows;
+			const double* const TW = T + 128 * (w & 1) + static_cast<long>(w >> 1) * ldt;
+			auto entry = [&](int i) { return __builtin_amdgcn_readfirstlane(tl[i]); };
+			auto tile_n0 = [&](int i) { return __builtin_amdgcn_readfirstlane(tl[i]) & 0xffff; };
+			auto tile_vg = [&](int i) { return __builtin_amdgcn_readfirstlane(tl[i]) >> 16; };
+
+			// the slab the next DMA fetches: tile ta (first column n0a), k-rows [ka, ka + 16)
+			int ta = 0, n0a = tile_n0(0) * BN, ka = 0;
+			auto advance = [&](int next_entry) { // next_entry = tl[ta + 1] (-1 behind the last tile)
+				ka += KB;
+				const bool wrap = ka == n0a + BN, has = next_entry >= 0;
+				// behind the last slab of the unit the iterator stays where it is: the two requests past the end re-fetch the last slab (never read)
+				ta = wrap && has ? ta + 1 : ta;
+				ka = wrap ? (has ? 0 : ka - KB) : ka;
+				n0a = wrap && has ? (next_entry & 0xffff) * BN : n0a;
+			};
+			auto stage_all = [&](int buf) {
+				const double* pA = KsW + static_cast<long>(ka) * rows;
+				const double* pB = TW + n0a + static_cast<long>(ka) * ldt;
+#pragma unroll
+				for (int i = 0; i < 6; ++i) dma(i < 2 ? pA : pB, voff[i], ldst[i], 8u * static_cast<unsigned>(buf * (i < 2 ? ASL : BSL)));
+			};
+			__syncthreads(); // the stage is free (previous unit)
+			stage_all(0);
+			advance(entry(1));
+			stage_all(1);
+			advance(entry(ta + 1));
+			asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); // slab 0 has landed (the six requests of slab 1 may still be out)
+			int p = 0; // buffer of the current step
+			double cA[AF], cB[BF]; // operands of the next MFMA group
+			auto read_ops = [&](int buf, int kk, double (&af)[AF], double (&bf)[BF]) {
+				const double* __restrict__ pa = As + buf * ASL + wm * (16 * AF) + fr;
+				const double* __restrict__ pb = Bs + buf * BSL + WNI * 16 + fr;
+#pragma unroll
+				for (int i = 0; i < AF; ++i) af[i] = pa[(kk + fk) * ASr + i * 16];
+#pragma unroll
+				for (int j = 0; j < BF; ++j) bf[j] = pb[(kk + fk) * BS + j * (16 * WN)];
+			};
+			read_ops(0, 0, cA, cB);
+			double rsq[AF];
+#pragma unroll
+			for (int i = 0; i < AF; ++i) rsq[i] = 0.0;
+			for (int ti = 0; ti < ntl; ++ti)
+			{
+				const int n0 = tile_n0(ti) * BN, vg = tile_vg(ti);
+				d4 acc[AF][BF];
+#pragma unroll
+				for (int i = 0; i < AF; ++i)
+#pragma unroll
+					for (int j = 0; j < BF; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+				// one k-step against the column blocks wn + WN t, t >= TMIN
+				auto kstep = [&](auto tmin_tag) {
+					constexpr int TMIN = decltype(tmin_tag)::value;
+					const int next_entry_v = tl[ta + 1]; // consumed in the middle of the step
+					// the slab this step's DMA fetches and where it goes (the buffer this step reads): scalar work, done while the MFMAs behind the last
+					// barrier still run — between a wave's last MFMA of the step and the barrier there is nothing but the barrier
+					const double* pA = KsW + static_cast<long>(ka) * rows;
+					const double* pB = TW + n0a + static_cast<long>(ka) * ldt;
+					unsigned poA = 8u * static_cast<unsigned>(p * ASL), poB = 8u * static_cast<unsigned>(p * BSL);
+					asm volatile("" : "+s"(pA), "+s"(pB), "+s"(poA), "+s"(poB)); // computed HERE (hipcc sinks them to their use behind the barrier otherwise)
+					double nA[AF], nB[BF];
+#pragma unroll
+					for (int kk = 4; kk < KB; kk += 4)
+					{
+						// (the order is pinned: hipcc otherwise gathers the reads of all groups in front of the barrier and sinks the MFMAs behind it)
+						read_ops(p, kk, nA, nB);
+						if (kk == 8) advance(__builtin_amdgcn_readfirstlane(next_entry_v));
+						__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+						for (int i = 0; i < AF; ++i)
+#pragma unroll
+							for (int j = TMIN; j < BF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(cB[j], cA[i], acc[i][j], 0, 0, 0);
+						__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+						for (int i = 0; i < AF; ++i) cA[i] = nA[i];
+#pragma unroll
+						for (int j = 0; j < BF; ++j) cB[j] = nB[j];
+					}
+					asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the next slab has landed; every wave holds its last operands of this one
+					p ^= 1;
+					read_ops(p, 0, nA, nB); // the next step's first operands: requested before anything else
+					__builtin_amdgcn_sched_barrier(0);
+					// the last MFMA group of this step with the six DMA issues of the slab after the next in between (into the buffer this step read)
+					constexpr int NM = AF * (BF - TMIN);
+					int issued = 0;
+#pragma unroll
+					for (int i = 0; i < AF; ++i)
+#pragma unroll
+						for (int j = TMIN; j < BF; ++j)
+						{
+							const int m = i * (BF - TMIN) + (j - TMIN);
+							if (m % 2 == 0 && issued < 6)
+							{
+								dma(issued < 2 ? pA : pB, voff[issued], ldst[issued], issued < 2 ? poA : poB);
+								++issued;
+							}
+							acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(cB[j], cA[i], acc[i][j], 0, 0, 0);
+							if (m % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+						}
+#pragma unroll
+					for (int r = (NM + 1) / 2 < 6 ? (NM + 1) / 2 : 6; r < 6; ++r) dma(r < 2 ? pA : pB, voff[r], ldst[r], r < 2 ? poA : poB);
+					__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+					for (int i = 0; i < AF; ++i) cA[i] = nA[i];
+#pragma unroll
+					for (int j = 0; j < BF; ++j) cB[j] = nB[j];
+				};
+				const int nd = n0 / KB;
+				for (int s = 0; s < nd; ++s) kstep(std::integral_constant<int, 0>{});
+				// diagonal 256-block: step D starts at k = n0 + 16 D, the column blocks jb < D are zero; jb = WNI + WN t >= D  <=>  t >= ceil((D - WNI) / WN)
+				[&]<int... D>(std::integer_sequence<int, D...>) {
+					(kstep(std::integral_constant<int, (D > WNI ? (D - WNI + WN - 1) / WN : 0)>{}), ...);
+				}(std::make_integer_sequence<int, BN / KB>{});
+#pragma unroll
+				for (int i = 0; i < AF; ++i)
+#pragma unroll
+					for (int j = 0; j < BF; ++j)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) rsq[i] = fma(acc[i][j][r], acc[i][j][r], rsq[i]);
+				// the last tile of a virtual group: its plane of partial sums (the WN column groups meet in LDS, beside the stage)
+				if (ti + 1 == ntl || tile_vg(ti + 1) != vg)
+				{
+#pragma unroll
+					for (int i = 0; i < AF; ++i)
+					{
+						double v = rsq[i];
+						v += __shfl_xor(v, 16);
+						v += __shfl_xor(v, 32);
+						if (lane < 16) red[WNI * BM + wm * (16 * AF) + 16 * i + lane] = v;
+						rsq[i] = 0.0;
+					}
+					__syncthreads();
+					if (threadIdx.x < BM)
+					{
+						double v = 0.0;
+#pragma unroll
+						for (int c = 0; c < WN; ++c) v += red[c * BM + threadIdx.x];
+						q[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = v;
+					}
+					__syncthreads();
+				}
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the two requests past the end
+		}
+		template <int AF, int BF, bool QUEUE>
+		__global__ void __launch_bounds__(NTHREADS, 1) rownormp_kernel(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt,
+			int n_total, double* __restrict__ q, long qstride, const Prune pr)
+		{
+			constexpr int KB = 16, WN = 16 / BF, ASr = BM + 16;
+			__shared__ __attribute__((aligned(16))) double lds[2 * KB * ASr + 2 * KB * BS + WN * BM];
+			__shared__ int tl[TL_MAX + 2];
+			__shared__ int s_ntl;
+			const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int wm = w / WN, wn = w % WN;
+			const int ntiles = n_total / BN;
+			int mblock, g, G;
+			for (int it = 0; next_unit<QUEUE>(pr, it, mblock, g, G); ++it)
+			{
+				const int m0 = mblock * BM;
+				__syncthreads(); // the previous unit's list has been read to the end
+				if (threadIdx.x == 0)
+				{
+					// the unit's tiles in the order (virtual group, tile): entry = tile | virtual group << 16, -1 behind the last
+					int c = 0;
+					for (int vg = 0; vg < VG; ++vg)
+					{
+						if (snake(vg, G) != g) continue;
+						for (int jt = 0; jt < ntiles; ++jt)
+							if (snake(jt, VG) == vg) tl[c++] = jt | (vg << 16);
+					}
+					tl[c] = -1, tl[c + 1] = -1;
+					s_ntl = c;
+				}
+				// a virtual group without a tile (n < 2048) still owns its plane of the partial sums
+				for (int vg = ntiles; vg < VG; ++vg)
+					if (snake(vg, G) == g && threadIdx.x < BM) q[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = 0.0;
+				__syncthreads();
+				const int ntl = __builtin_amdgcn_readfirstlane(s_ntl);
+				if (ntl == 0) continue; // uniform
+				if constexpr (WN == 4)
+				{
+					if (wn == 0) rownormp_unit<AF, BF, 0>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
+					else if (wn == 1) rownormp_unit<AF, BF, 1>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
+					else if (wn == 2) rownormp_unit<AF, BF, 2>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
+					else rownormp_unit<AF, BF, 3>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
+				}
+				else
+				{
+					if (wn == 0) rownormp_unit<AF, BF, 0>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
+					else rownormp_unit<AF, BF, 1>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
+				}
+			}
+		}
+
 		// ---- the same contraction for SHORT factors (n <= 512: one or two N-tiles) and few row blocks — C1: N = 256, 128 x 128 grid ----------
 		// rownorm2_kernel<2,8> gives such a launch 128 workgroups of 16 k-steps for 256 CUs, and every step waits for its slab's DMA round trip
 		// (~2.5 us against ~1 us of MFMA work in the diagonal tile): 47 us for 1.1 GFLOP, 0.29 of the peak.  Here a workgroup takes 64 rows (twice
@@ -970,6 +1208,13 @@ namespace gple
 			const char* e = getenv("GPLE_ROWNORM_SHORT");
 			return e == nullptr || atoi(e) != 0;
 		}();
+		// the k-steps of a unit as one pipeline (rownormp_kernel; same bits).  GPLE_ROWNORM_PIPE=0: rownorm2_kernel, A/B
+		static const bool pipe_env = [] {
+			const char* e = getenv("GPLE_ROWNORM_PIPE");
+			return (e == nullptr || atoi(e) != 0);
+		}();
+		const bool pipe = ctx->rownorm_pipe < 0 ? pipe_env : ctx->rownorm_pipe != 0;
+		if (a.n_total / BN > TL_MAX) return hipErrorInvalidValue;
 		const bool short_factor = short_ok && variant == 3 && a.n_total / BN <= 2 && a.m_rows / BM <= 2 * device_cu_count();
 		double* Ks = scratch;
 		double* mu_part = scratch + static_cast<size_t>(chunk_rows) * a.n_total;
@@ -1004,7 +1249,9 @@ namespace gple
 				if (queue_mode) hipLaunchKernelGGL(queue_kernel, grid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
 				else hipLaunchKernelGGL(full_kernel, grid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
 			};
-			if (variant == 3) launch(rownorm2_kernel<2, 8, false>, rownorm2_kernel<2, 8, true>);
+			if (variant == 3 && pipe) launch(rownormp_kernel<2, 8, false>, rownormp_kernel<2, 8, true>);
+			else if (variant == 2 && pipe) launch(rownormp_kernel<4, 4, false>, rownormp_kernel<4, 4, true>);
+			else if (variant == 3) launch(rownorm2_kernel<2, 8, false>, rownorm2_kernel<2, 8, true>);
 			else if (variant == 2) launch(rownorm2_kernel<4, 4, false>, rownorm2_kernel<4, 4, true>);
 			else launch(rownorm_kernel<8, 16, false>, rownorm_kernel<8, 16, true>);
 		};

@@ -642,6 +642,37 @@ def test_short_factor_kernel_has_the_bits_of_the_general_one(gpu, N):
     fit.release()
 
 
+@pytest.mark.parametrize("N,M,cplx", [(1024, 40000, False), (700, 9000, True), (2300, 9000, False), (4096, 6100, False), (4096, 40000, False), (1500, 20000, True)])
+def test_rownorm_variants_agree_bit_for_bit(gpu, N, M, cplx):
+    """rownormp_kernel (the k-steps of a unit as one pipeline: operands of the next step requested right behind the barrier, the DMA issues between
+    the MFMAs of the last group, slabs requested across tile boundaries) against rownorm2_kernel (barrier-to-barrier k-steps): per accumulator
+    the same MFMAs in the same order and the same sums behind them, so every output must agree bit for bit — full contraction (static grid,
+    every split of the N-tiles) and the pruned one (work queue), real and complex (typed rows), 2 x 8 and 4 x 4 blocking"""
+    import ctypes
+    from tests.test_gpu_configs import config_inputs, THETA_R, THETA_C
+    X, y, grid, _ = config_inputs(N, 64, 5, cplx=cplx) if cplx else config_inputs(N, 64, 5)
+    rng = np.random.default_rng(N + M)
+    near = X[rng.integers(0, N, M // 2)] + rng.normal(0, 0.3, (M // 2, 2))
+    far = X[rng.integers(0, N, M - M // 2)] + rng.normal(0, 6.0, (M - M // 2, 2))  # many of these are pruned by the default predict
+    pts = np.concatenate([near, far])[rng.permutation(M)]
+    fit = gpu.complex_fit(THETA_C, X, y, 0) if cplx else gpu.real_fit(THETA_R, X, y, 0)
+    pred = gpu.complex_predict if cplx else gpu.real_predict
+    knob = gpu.lib.gple_debug_predict_knobs
+    knob.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    out = {}
+    try:
+        for v in (0, 1):
+            assert knob(gpu.ctx, v) == 0
+            out[v] = (pred(fit, pts, flags=c.PREDICT_FULL), pred(fit, pts))
+    finally:
+        knob(gpu.ctx, 2)
+    for leg in (0, 1):
+        for k in ("prediction", "variance", "cutoff"):
+            assert np.array_equal(out[0][leg][k], out[1][leg][k]), (leg, k)
+    assert np.isfinite(out[1][0]["variance"]).all() and (out[1][0]["variance"] < 0.5 * out[1][0]["variance"].max()).any()
+    fit.release()
+
+
 def test_forced_128_tiles_on_odd_fork_points_stay_off_unwritten_blocks():
     """the block-row inverse runs its triangular GEMMs on sub-matrices whose origin is a fork point — a multiple of 64 only.  A
     128-tile with a triangular k-range starts at its 128-aligned diagonal tile and would take in a block above the diagonal that nobody writes
