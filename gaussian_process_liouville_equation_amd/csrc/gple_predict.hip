@@ -696,10 +696,10 @@ namespace gple
 					}
 					asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the next slab has landed; every wave holds its last operands of this one
 					p ^= 1;
-					read_ops(p, 0, nA, nB); // the next step's first operands: requested before anything else
-					__builtin_amdgcn_sched_barrier(0);
-					// the last MFMA group of this step with the six DMA issues of the slab after the next in between (into the buffer this step read)
-					constexpr int NM = AF * (BF - TMIN);
+					// behind the barrier: LEAD MFMAs of the step's last group at once (their operands were read in front of the barrier), then the requests
+					// for the next step's first operands, then the six DMA issues of the slab after the next (into the buffer this step read) between
+					// the group's other MFMAs.  LEAD: measured on one box, 4 x 4: 2 leads 0 by 0.6 % at C4r; 2 x 8 (ten operand requests): 0 leads 2 by 0.5 % at C2
+					constexpr int NM = AF * (BF - TMIN), LEAD = AF == 4 ? 2 : 0;
 					int issued = 0;
 #pragma unroll
 					for (int i = 0; i < AF; ++i)
@@ -707,7 +707,12 @@ namespace gple
 						for (int j = TMIN; j < BF; ++j)
 						{
 							const int m = i * (BF - TMIN) + (j - TMIN);
-							if (m % 2 == 0 && issued < 6)
+							if (m == LEAD)
+							{
+								read_ops(p, 0, nA, nB);
+								__builtin_amdgcn_sched_barrier(0);
+							}
+							if (m >= LEAD && (m - LEAD) % 2 == 0 && issued < 6)
 							{
 								dma(issued < 2 ? pA : pB, voff[issued], ldst[issued], issued < 2 ? poA : poB);
 								++issued;
@@ -715,8 +720,14 @@ namespace gple
 							acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(cB[j], cA[i], acc[i][j], 0, 0, 0);
 							if (m % 2 == 1) __builtin_amdgcn_sched_barrier(0);
 						}
+					if constexpr (NM <= LEAD)
+					{
+						__builtin_amdgcn_sched_barrier(0);
+						read_ops(p, 0, nA, nB);
+						__builtin_amdgcn_sched_barrier(0);
+					}
 #pragma unroll
-					for (int r = (NM + 1) / 2 < 6 ? (NM + 1) / 2 : 6; r < 6; ++r) dma(r < 2 ? pA : pB, voff[r], ldst[r], r < 2 ? poA : poB);
+					for (int r = NM > LEAD ? ((NM - LEAD + 1) / 2 < 6 ? (NM - LEAD + 1) / 2 : 6) : 0; r < 6; ++r) dma(r < 2 ? pA : pB, voff[r], ldst[r], r < 2 ? poA : poB);
 					__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 					for (int i = 0; i < AF; ++i) cA[i] = nA[i];
@@ -769,7 +780,12 @@ namespace gple
 			__shared__ int tl[TL_MAX + 2];
 			__shared__ int s_ntl;
 			const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-			const int wm = w / WN, wn = w % WN;
+			// wave -> (row group wm, column group wn).  Waves w and w + 4 share a SIMD, and inside the diagonal 256-block a column group's live blocks
+			// thin out at its own pace (group wn keeps the blocks wn + WN t >= D): with wn = w % WN both waves of a SIMD belong to the same column
+			// group and the SIMD of the last group works up to a block per step longer than the first one's while all meet at the barrier.  Here
+			// a SIMD's two waves take column groups that thin out in opposite phase (wn and WN - 1 - wn); which wave computes what changes nothing in the sums
+			const int simd = w & 3, half = w >> 2;
+			const int wm = WN == 4 ? half : simd, wn = WN == 4 ? (half ? 3 - simd : simd) : (half ^ (simd & 1));
 			const int ntiles = n_total / BN;
 			int mblock, g, G;
 			for (int it = 0; next_unit<QUEUE>(pr, it, mblock, g, G); ++it)
