@@ -47,7 +47,7 @@ WORKLOADS = {  # name: (N, G, kernel)
     "NLML4096": (4096, 256, "nlml"),
 }
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak; measured 78.4 with v_mfma_f64_16x16x4_f64
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 # density-matrix elements in the reference's order (lower triangle, row-major: storage.h / predict.cpp:290-360)
 ELEMENT_KINDS = {"elements2": ["real", "complex", "real"], "elements3": ["real", "complex", "real", "complex", "complex", "real"]}
 
@@ -526,6 +526,7 @@ def main():
     _, fit_total, fit_cnt = api.timing(0)
     _, pred_total, pred_cnt = api.timing(1)
     _, pk_total, pk_cnt = api.timing(2)  # HIP events around every rownorm_kernel launch (the K* chunks of one predict)
+    contraction_kernel = api.last_contraction_kernel()  # what the timed steps ran on (asked before the pruned leg below launches its own)
     pk_ms = pk_total / max(1, pk_cnt)    # average duration of ONE launch (what rocprofv3 --stats reports)
     launches_per_step = pk_cnt / max(1, args.steps)
     m_local = hi - lo
@@ -562,7 +563,7 @@ def main():
                    "N": N, "M": M, "parallelism": (f"{world} independent density-matrix elements, one per GPU, no data-path collective" if by_element else
                                    f"grid-sharded x{world}, replicated fit, {'RCCL' if args.backend == 'nccl' else 'gloo (host)'} all-gather") if world > 1 else "single GPU",
                    "via": args.via, "collective": via_note},
-        "roofline": {"bound": "mfma", "kernel": ("rownorm2_kernel<4,4,false>" if nn >= 2048 else "rownorm2_kernel<2,8,false>") + " (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
+        "roofline": {"bound": "mfma", "kernel": contraction_kernel + " (fp64 MFMA triangular contraction ||T k*||^2 over one K* chunk)",
                      "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(pk_ms, 4), "launches_per_step": launches_per_step,
                      "algorithmic_flops_per_launch": flops,
@@ -775,7 +776,7 @@ def elements_step(args, pkg, c, parallel, torch, dist, rank, world, dev):
                                                    else ("none (one rank)" if world == 1 else "torch.distributed all_gather_into_tensor"
                                                          + (f" — FALLBACK, the library-side communicator failed: {fallback}" if fallback else ""))),
                    "plan": plan.describe()},
-        "roofline": {"bound": "mfma", "kernel": "rownorm2_kernel<4,4,false> (fp64 MFMA triangular contraction ||T k*||^2), all elements of this rank",
+        "roofline": {"bound": "mfma", "kernel": api.last_contraction_kernel() + " (fp64 MFMA triangular contraction ||T k*||^2), all elements of this rank",
                      "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": None,
                      "kernel_ms": round(pk_total / max(1, pk_cnt), 4), "launches_per_step": pk_cnt / max(1, args.steps),
                      "algorithmic_flops_per_step_this_rank": flops_rank},

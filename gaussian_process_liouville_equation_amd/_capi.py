@@ -388,6 +388,12 @@ class Api:
         self._check(self.lib.gple_ctx_get_timing(self.ctx, which, C.byref(last), C.byref(total), C.byref(count)))
         return last.value, total.value, count.value
 
+    def last_contraction_kernel(self):
+        """Name of the kernel this context's last predict ran its variance contraction on (csrc/gple_debug.h; the roofline label of bench.py)."""
+        fn = self.lib.gple_debug_last_contraction_kernel
+        fn.argtypes, fn.restype = [C.c_void_p], C.c_char_p
+        return (fn(self.ctx) or b"").decode()
+
     def prune_stats(self, reset=False):
         """(contracted, seen) test rows of the pruned predicts in units of 128 rows since creation / the last reset."""
         a, b = C.c_ulonglong(), C.c_ulonglong()

@@ -2710,6 +2710,7 @@ extern "C"
 		if (recoveries) *recoveries = ctx->dag_recoveries;
 		return GPLE_OK;
 	}
+	const char* gple_debug_last_contraction_kernel(gple_ctx* ctx) { return ctx ? ctx->last_contraction : ""; }
 	int gple_debug_predict_knobs(gple_ctx* ctx, int rownorm_pipe)
 	{
 		if (!ctx) return GPLE_ERR_BAD_ARG;

@@ -42,6 +42,8 @@ extern "C"
 	 * k-step), 1 = rownormp_kernel (the k-steps of a unit as one pipeline), 2 = back to the environment's (GPLE_ROWNORM_PIPE); negative: unchanged.
 	 * The two must agree bit for bit (tests/test_gpu_parity.py). */
 	int gple_debug_predict_knobs(gple_ctx* ctx, int rownorm_pipe);
+	/* Name of the kernel the last predict of this context ran its variance contraction on ("" before the first one; bench.py's roofline label). */
+	const char* gple_debug_last_contraction_kernel(gple_ctx* ctx);
 #ifdef __cplusplus
 }
 #endif

@@ -1265,11 +1265,11 @@ namespace gple
 				if (queue_mode) hipLaunchKernelGGL(queue_kernel, grid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
 				else hipLaunchKernelGGL(full_kernel, grid, dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qdst, static_cast<long>(a.m_rows), pr);
 			};
-			if (variant == 3 && pipe) launch(rownormp_kernel<2, 8, false>, rownormp_kernel<2, 8, true>);
-			else if (variant == 2 && pipe) launch(rownormp_kernel<4, 4, false>, rownormp_kernel<4, 4, true>);
-			else if (variant == 3) launch(rownorm2_kernel<2, 8, false>, rownorm2_kernel<2, 8, true>);
-			else if (variant == 2) launch(rownorm2_kernel<4, 4, false>, rownorm2_kernel<4, 4, true>);
-			else launch(rownorm_kernel<8, 16, false>, rownorm_kernel<8, 16, true>);
+			if (variant == 3 && pipe) { launch(rownormp_kernel<2, 8, false>, rownormp_kernel<2, 8, true>); ctx->last_contraction = queue_mode ? "rownormp_kernel<2,8,true>" : "rownormp_kernel<2,8,false>"; }
+			else if (variant == 2 && pipe) { launch(rownormp_kernel<4, 4, false>, rownormp_kernel<4, 4, true>); ctx->last_contraction = queue_mode ? "rownormp_kernel<4,4,true>" : "rownormp_kernel<4,4,false>"; }
+			else if (variant == 3) { launch(rownorm2_kernel<2, 8, false>, rownorm2_kernel<2, 8, true>); ctx->last_contraction = queue_mode ? "rownorm2_kernel<2,8,true>" : "rownorm2_kernel<2,8,false>"; }
+			else if (variant == 2) { launch(rownorm2_kernel<4, 4, false>, rownorm2_kernel<4, 4, true>); ctx->last_contraction = queue_mode ? "rownorm2_kernel<4,4,true>" : "rownorm2_kernel<4,4,false>"; }
+			else { launch(rownorm_kernel<8, 16, false>, rownorm_kernel<8, 16, true>); ctx->last_contraction = queue_mode ? "rownorm_kernel<8,16,true>" : "rownorm_kernel<8,16,false>"; }
 		};
 		if (prune || cut_only)
 		{
@@ -1340,10 +1340,14 @@ namespace gple
 					g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
 					const hipError_t e = launch_gemm(s, g, gemm_pick_tile(a.n_total, rows, 1, true));
 					if (e != hipSuccess) return e;
+					ctx->last_contraction = "gemm_f64 (Z = T K*^T) + colsumsq_kernel";
 					hipLaunchKernelGGL(colsumsq_kernel, dim3(rows), dim3(256), 0, s, Z, static_cast<long>(a.n_total), a.n_total, a.q + row0);
 				}
 				else if (short_factor)
+				{
+					ctx->last_contraction = "rownorm3_kernel";
 					hipLaunchKernelGGL(rownorm3_kernel, dim3(rows / 64, split), dim3(NTHREADS), 0, s, Ks, rows, a.T, a.ldt, a.n_total, qpart + row0, static_cast<long>(a.m_rows));
+				}
 				else
 					launch_rownorm(false, dim3(rows / BM, split), rows, qpart + row0, Prune{});
 				chunk_timer_stop(ctx);
