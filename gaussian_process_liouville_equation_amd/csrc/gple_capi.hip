@@ -2711,11 +2711,12 @@ extern "C"
 		return GPLE_OK;
 	}
 	const char* gple_debug_last_contraction_kernel(gple_ctx* ctx) { return ctx ? ctx->last_contraction : ""; }
-	int gple_debug_predict_knobs(gple_ctx* ctx, int rownorm_pipe)
+	int gple_debug_predict_knobs(gple_ctx* ctx, int rownorm_pipe, int fused_small)
 	{
 		if (!ctx) return GPLE_ERR_BAD_ARG;
 		std::lock_guard<std::mutex> lk(ctx->call_mu);
 		if (rownorm_pipe >= 0) ctx->rownorm_pipe = rownorm_pipe >= 2 ? -1 : rownorm_pipe;
+		if (fused_small >= 0) ctx->fused_small = fused_small >= 2 ? -1 : fused_small;
 		return GPLE_OK;
 	}
 	int gple_debug_chol_layout(int n, int cap, int* bounds, int* nb, int* forks, int* nf, unsigned long long* work_doubles)

@@ -38,10 +38,12 @@ extern "C"
 	 * wave of the one-launch scheme gives up (0 = the default, 2^21); dag_blocks: workgroups of its launches (0 = one per CU).  giveups / recoveries
 	 * (nullable): how often the host has seen info = -1 on this context / repeated a factorisation with a launch per panel because of it. */
 	int gple_debug_chol_knobs(gple_ctx* ctx, int scheme, int poll_limit, int dag_blocks, long* giveups, long* recoveries);
-	/* Test knob of the predict path on ONE context: which contraction kernel its large predicts run on — 0 = rownorm2_kernel (a barrier-to-barrier
-	 * k-step), 1 = rownormp_kernel (the k-steps of a unit as one pipeline), 2 = back to the environment's (GPLE_ROWNORM_PIPE); negative: unchanged.
-	 * The two must agree bit for bit (tests/test_gpu_parity.py). */
-	int gple_debug_predict_knobs(gple_ctx* ctx, int rownorm_pipe);
+	/* Test knobs of the predict path on ONE context; 0 / 1 set a knob, 2 hands it back to the environment, a negative argument leaves it alone.
+	 * rownorm_pipe: the contraction kernel of large predicts — 0 = rownorm2_kernel (a barrier-to-barrier k-step), 1 = rownormp_kernel (the k-steps
+	 * of a unit as one pipeline); environment: GPLE_ROWNORM_PIPE.  fused_small: real fits with N <= 256 — 0 = K* generation, contraction and sums
+	 * as separate kernels, 1 = predict_fused256_kernel; environment: GPLE_PREDICT_FUSED_SMALL.  Either pair must agree bit for bit
+	 * (tests/test_gpu_parity.py). */
+	int gple_debug_predict_knobs(gple_ctx* ctx, int rownorm_pipe, int fused_small);
 	/* Name of the kernel the last predict of this context ran its variance contraction on ("" before the first one; bench.py's roofline label). */
 	const char* gple_debug_last_contraction_kernel(gple_ctx* ctx);
 #ifdef __cplusplus

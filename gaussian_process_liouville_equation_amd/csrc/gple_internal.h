@@ -87,6 +87,7 @@ namespace gple
 		// per panel, 1: one launch per outer block), polls before a wave of the one-launch scheme gives up, workgroups of its launches (0: defaults)
 		int chol_scheme = -1, dag_poll_limit = 0, dag_blocks = 0;
 		const char* last_contraction = ""; // the kernel the last large predict's contraction ran on (gple_debug_last_contraction_kernel)
+		int fused_small = -1;  // gple_debug_predict_knobs: -1 = GPLE_PREDICT_FUSED_SMALL's choice, 0 = separate kernels, 1 = predict_fused256_kernel where it applies
 		int rownorm_pipe = -1; // gple_debug_predict_knobs: -1 = GPLE_ROWNORM_PIPE's choice, 0 = rownorm2_kernel, 1 = rownormp_kernel (same bits)
 		long dag_giveups = 0, dag_recoveries = 0; // give-ups seen by the host / factorisations repeated with a launch per panel because of one
 		std::vector<hipEvent_t> side_forks;

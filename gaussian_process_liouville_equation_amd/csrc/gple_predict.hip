@@ -948,6 +948,143 @@ namespace gple
 			}
 		}
 
+		// ---- ONE launch for the real GP with n = 256 (N <= 256: the size the reference itself runs, C1) ----------------------------------------
+		// kstar_gen_kernel + rownorm3_kernel + two sum_mu_kernel launches are 15 + 35 + 5 + 5 us at C1 (128 x 128 grid) with the gaps between them,
+		// for 14 us of MFMA work.  With ONE N-tile nothing of K* is ever used twice, so the argument against generating it inside the contraction
+		// (a fused kernel regenerates every entry once per N-tile) does not apply: here a workgroup of 64 rows generates the K* slab
+		// of the NEXT k-step in registers (two entries per thread: rows t & 63, k-rows w and w + 8 of the slab) while the MFMAs of the current one
+		// run, writes it to LDS in front of the step's barrier, and streams the slabs of T by LDS-DMA two steps ahead (three stages).  The fp64
+		// exponentials and the MFMAs share the SIMD's pipe, so their times add (7.5 + 14.5 us) — but nothing goes through HBM in between and
+		// nothing waits for a launch.  The mean rides along: wave 0 walks its 64 rows' k-chain over the slab in LDS.
+		// Same bits as the kernels it replaces, by construction: K* entries by the expression of kstar_gen_kernel, the partial means as chains
+		// over the same k-ranges (gen_ksplit) added in the same order (sum_mu_kernel), the contraction with rownorm3_kernel's fragments, k order
+		// and sums (test_fused_small_predict_has_the_bits_of_the_unfused_path).
+		template <int WNI>
+		__device__ __forceinline__ void fused256_wave(const PredictArgs& a, int ksplit, double* lds, int m0, int wm)
+		{
+			constexpr int KB = 16, BF = 8, WN = 2, NST = 3, TM = 64;
+			constexpr int ASr = TM + 16, ASL = KB * ASr, BSL = KB * BS;
+			double* const As = lds;
+			double* const Bs = lds + 2 * ASL;
+			double* const red = Bs + NST * BSL;
+			double* const vs = red + WN * TM;
+			const int t = threadIdx.x, lane = t & 63;
+			const int fk = lane >> 4, fr = lane & 15;
+			const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+			auto lds_addr = [](const double* p) { return static_cast<unsigned>(reinterpret_cast<unsigned long>((__attribute__((address_space(3))) const double*)p)); };
+			auto dma = [](const double* base, unsigned voff, unsigned ldst) {
+				asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(ldst), "s"(base) : "memory");
+			};
+			// T slab s (k-rows 16 s ..): wave w fills half (w & 1) of the k-rows (w >> 1) + 4 qq
+			const double* const TW = a.T + 128 * (w & 1) + static_cast<long>(w >> 1) * a.ldt;
+			auto stage_b = [&](int s) {
+#pragma unroll
+				for (int qq = 0; qq < 4; ++qq)
+					dma(TW + static_cast<long>(s) * KB * a.ldt, 16u * lane + 32u * static_cast<unsigned>(a.ldt) * qq,
+						lds_addr(Bs) + 8u * static_cast<unsigned>((s % NST) * BSL + ((w >> 1) + 4 * qq) * BS + 128 * (w & 1)));
+			};
+			// this thread's test point (rows beyond M are clamped: their results are never read) and its two K* entries of slab s
+			const int gm = m0 + lane;
+			const int pidx = gm < a.M ? gm : a.M - 1;
+			const double xm = a.Xs[2 * pidx], pm = a.Xs[2 * pidx + 1];
+			const SEParam& sp = a.ps.p[0];
+			auto kstar = [&](int k) {
+				const bool valid = k < a.N;
+				const int pc = valid ? k : 0;
+				const double xk = a.Xt[2 * pc], pkv = a.Xt[2 * pc + 1]; // uniform: scalar loads
+				const double d0 = __dmul_rn(xm - xk, sp.rl0), d1 = __dmul_rn(pm - pkv, sp.rl1);
+				const double g = exp_nonpos(__dmul_rn(-0.5, fma(d0, d0, __dmul_rn(d1, d1))));
+				const double delta = (xm == xk && pm == pkv) ? sp.n2 : 0.0; // delta_kernel: exact equality, kernel.cpp:26
+				return valid ? __dmul_rn(sp.amp, g + delta) : 0.0;
+			};
+			if (t < BN) vs[t] = a.v[t];
+			stage_b(0);
+			stage_b(1);
+			As[w * ASr + lane] = kstar(w), As[(w + 8) * ASr + lane] = kstar(w + 8);
+			asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); // slab 0 of T has landed, slab 0 of K* is written
+			d4 acc[BF];
+#pragma unroll
+			for (int j = 0; j < BF; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+			const int kper = BN / ksplit; // k-range of one partial mean (kstar_gen_kernel): 32 ... 4
+			double mu = 0.0, msum = 0.0;
+			auto kstep = [&](auto d_tag) {
+				constexpr int D = decltype(d_tag)::value;
+				constexpr int TMIN = D > WNI ? (D - WNI + WN - 1) / WN : 0;
+				if constexpr (D + 2 < BN / KB) stage_b(D + 2); // into the stage step D - 1 read
+				double e0 = 0.0, e1 = 0.0;
+				if constexpr (D + 1 < BN / KB) e0 = kstar(KB * (D + 1) + w), e1 = kstar(KB * (D + 1) + w + 8);
+				const double* __restrict__ pa = As + (D & 1) * ASL;
+				const double* __restrict__ pb = Bs + (D % NST) * BSL + WNI * 16 + fr;
+				if (w == 0)
+				{
+					// the mean of rows m0 .. m0 + 63: one chain per k-range of kper entries, the ranges added in order (sum_mu_kernel)
+#pragma unroll
+					for (int k = 0; k < KB; ++k)
+					{
+						const bool first = ((KB * D + k) & (kper - 1)) == 0;
+						msum = first ? msum + mu : msum;
+						mu = first ? 0.0 : mu;
+						mu = fma(pa[k * ASr + lane], vs[KB * D + k], mu);
+					}
+				}
+#pragma unroll
+				for (int kk = 0; kk < KB; kk += 4)
+				{
+					const double af = pa[(kk + fk) * ASr + wm * 16 + fr];
+					double bf[BF];
+#pragma unroll
+					for (int j = TMIN; j < BF; ++j) bf[j] = pb[(kk + fk) * BS + j * (16 * WN)];
+#pragma unroll
+					for (int j = TMIN; j < BF; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af, acc[j], 0, 0, 0);
+				}
+				if constexpr (D + 1 < BN / KB)
+				{
+					double* __restrict__ pn = As + ((D + 1) & 1) * ASL; // read in step D - 1: every wave is past that step's barrier
+					pn[w * ASr + lane] = e0, pn[(w + 8) * ASr + lane] = e1;
+				}
+				if constexpr (D + 2 < BN / KB) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+				else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			};
+			[&]<int... D>(std::integer_sequence<int, D...>) { (kstep(std::integral_constant<int, D>{}), ...); }(std::make_integer_sequence<int, BN / KB>{});
+			double rsq = 0.0;
+#pragma unroll
+			for (int j = 0; j < BF; ++j)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) rsq = fma(acc[j][r], acc[j][r], rsq);
+			double v = rsq;
+			v += __shfl_xor(v, 16);
+			v += __shfl_xor(v, 32);
+			if (lane < 16) red[WNI * TM + wm * 16 + lane] = v;
+			__syncthreads();
+			if (t < TM)
+			{
+				double sum = 0.0;
+#pragma unroll
+				for (int c = 0; c < WN; ++c) sum += red[c * TM + t];
+				double qv = 0.0; // the VG planes in order: plane 0 holds the one N-tile, the others are zero
+				qv += sum;
+				a.q[m0 + t] = qv;
+				a.mu[m0 + t] = msum + mu; // (w == 0 for these threads) the last k-range
+			}
+		}
+		__global__ void __launch_bounds__(NTHREADS, 1) predict_fused256_kernel(const PredictArgs a, int ksplit)
+		{
+			constexpr int KB = 16, TM = 64, WN = 2, NST = 3;
+			__shared__ __attribute__((aligned(16))) double lds[2 * KB * (TM + 16) + NST * KB * BS + WN * TM + BN];
+			const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int simd = w & 3, half = w >> 2;
+			const int wm = simd, wn = half ^ (simd & 1); // a SIMD's two waves on the two column groups (they thin out in opposite phase)
+			const int m0 = blockIdx.x * TM;
+			if (blockIdx.x == 0 && threadIdx.x == 0 && a.prune_thr > 0.0 && a.prune_stats != nullptr)
+			{
+				// a pruned predict that landed here contracted every row (cheaper than the statistics pass at this size; same bits either way)
+				atomicAdd(a.prune_stats, static_cast<unsigned long long>(a.m_rows / BM));
+				atomicAdd(a.prune_stats + 1, static_cast<unsigned long long>(a.m_rows / BM));
+			}
+			if (wn == 0) fused256_wave<0>(a, ksplit, lds, m0, wm);
+			else fused256_wave<1>(a, ksplit, lds, m0, wm);
+		}
+
 		// ---- a handful of test points (the one-point predicts of main.cpp:75-101, evolve.cpp:298, mc.cpp:158-172) --------------
 		// For M <= FEW_MAX typed rows the tiled paths pad to 128 rows, materialise K* and run a GEMM against all of T: 0.1-0.65 ms
 		// per call, almost all of it launches, padding and copies.  Here the contraction is a triangular mat-vec per point with K*
@@ -1254,6 +1391,20 @@ namespace gple
 			if (e != hipSuccess) return e;
 			hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.mu);
 			if (a.dv) hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, dplanes), dim3(256), 0, s, mu_part, a.m_rows, ksplit, a.dacc);
+			return hipGetLastError();
+		}
+		// the real GP with one N-tile (N <= 256): generation, contraction and both sums in one launch, whatever the number of rows; a pruned request
+		// contracts every row there (same bits, cheaper than the statistics pass).  GPLE_PREDICT_FUSED_SMALL=0: the separate kernels, A/B
+		static const bool fused_env = [] {
+			const char* e = getenv("GPLE_PREDICT_FUSED_SMALL");
+			return e == nullptr || atoi(e) != 0;
+		}();
+		if ((ctx->fused_small < 0 ? fused_env : ctx->fused_small != 0) && a.n_total == BN && a.m_split == a.m_rows && !a.dv && !(a.cut_thr > 0.0))
+		{
+			chunk_timer_start(ctx);
+			ctx->last_contraction = "predict_fused256_kernel";
+			hipLaunchKernelGGL(predict_fused256_kernel, dim3(a.m_rows / 64), dim3(NTHREADS), 0, s, a, ksplit);
+			chunk_timer_stop(ctx);
 			return hipGetLastError();
 		}
 		// the variance only decides the cut-off factor: points whose mean is large enough for factor 1 whatever the variance are not contracted

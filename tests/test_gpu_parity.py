@@ -658,18 +658,61 @@ def test_rownorm_variants_agree_bit_for_bit(gpu, N, M, cplx):
     fit = gpu.complex_fit(THETA_C, X, y, 0) if cplx else gpu.real_fit(THETA_R, X, y, 0)
     pred = gpu.complex_predict if cplx else gpu.real_predict
     knob = gpu.lib.gple_debug_predict_knobs
-    knob.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    knob.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     out = {}
     try:
         for v in (0, 1):
-            assert knob(gpu.ctx, v) == 0
+            assert knob(gpu.ctx, v, -1) == 0
             out[v] = (pred(fit, pts, flags=c.PREDICT_FULL), pred(fit, pts))
     finally:
-        knob(gpu.ctx, 2)
+        knob(gpu.ctx, 2, -1)
     for leg in (0, 1):
         for k in ("prediction", "variance", "cutoff"):
             assert np.array_equal(out[0][leg][k], out[1][leg][k]), (leg, k)
     assert np.isfinite(out[1][0]["variance"]).all() and (out[1][0]["variance"] < 0.5 * out[1][0]["variance"].max()).any()
+    fit.release()
+
+
+@pytest.mark.parametrize("N,M", [(256, 16384), (200, 16384), (256, 1300), (37, 300), (129, 50000)])
+def test_fused_small_predict_has_the_bits_of_the_unfused_path(gpu, oracle, N, M):
+    """Real fits with N <= 256 (one N-tile of T; C1, the size the reference itself runs) predict in ONE launch (predict_fused256_kernel: K* generated
+    inside the contraction, the mean chained over the slab in LDS, both sums in the kernel).  Against the separate kernels (K* generation,
+    rownorm3_kernel / rownorm2_kernel<2,8>, two sum kernels) every output must agree bit for bit: same K* expression, same k-ranges of the
+    partial means added in the same order, the same fragments and sums in the contraction.  Full and default (pruned) request; against the
+    oracle as well, so that the pair cannot be wrong together."""
+    import ctypes
+    from tests.test_gpu_configs import config_inputs, THETA_R
+    X, y, grid, _ = config_inputs(N, 64, 5)
+    rng = np.random.default_rng(N + M)
+    pts = np.concatenate([X[rng.integers(0, N, M // 2)] + rng.normal(0, 0.3, (M // 2, 2)), X[rng.integers(0, N, M - M // 2)] + rng.normal(0, 5.0, (M - M // 2, 2))])
+    pts[:7] = X[:7]  # coincident points: the delta kernel
+    fit = gpu.real_fit(THETA_R, X, y, 0)
+    knob = gpu.lib.gple_debug_predict_knobs
+    knob.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    last = gpu.lib.gple_debug_last_contraction_kernel
+    last.argtypes, last.restype = [ctypes.c_void_p], ctypes.c_char_p
+    out, ran = {}, {}
+    try:
+        for v in (0, 1):
+            assert knob(gpu.ctx, -1, v) == 0
+            out[v] = (gpu.real_predict(fit, pts, flags=c.PREDICT_FULL), gpu.real_predict(fit, pts))
+            ran[v] = last(gpu.ctx).decode()
+    finally:
+        knob(gpu.ctx, -1, 2)
+    assert ran[1] == "predict_fused256_kernel" and ran[0] != ran[1], ran
+    streaming = ran[0].startswith("rownorm")  # few rows go through Z = T K*^T and column sums when unfused: another order of the same sums
+    for leg in (0, 1):
+        assert np.array_equal(out[0][leg]["prediction"], out[1][leg]["prediction"]), leg
+        for k in ("variance", "cutoff"):
+            if streaming:
+                assert np.array_equal(out[0][leg][k], out[1][leg][k]), (leg, k, np.abs(out[0][leg][k] - out[1][leg][k]).max())
+            else:
+                assert np.abs(out[0][leg][k] - out[1][leg][k]).max() < 1e-11, (leg, k)
+    assert streaming == (M >= 8192)
+    fo = oracle.real_fit(THETA_R, X, y, 0)
+    po = oracle.real_predict(fo, pts[:2000])
+    assert np.abs(out[1][0]["prediction"][:2000] - po["prediction"]).max() < 1e-9 * max(1.0, np.abs(po["prediction"]).max())
+    assert np.abs(out[1][0]["variance"][:2000] - po["variance"]).max() < 1e-9
     fit.release()
 
 
