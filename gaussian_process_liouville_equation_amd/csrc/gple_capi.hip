@@ -1322,7 +1322,7 @@ extern "C"
 			}
 		}
 		int chunk_rows = 0;
-		bool few_rows = false;
+		bool few_rows = false, late_contraction = false, finished = false;
 		Scratch kstar(ctx);
 		if (predict_is_few(a)) // one-point predicts of the reference's callers: no padding, no K*, no GEMM
 		{
@@ -1332,7 +1332,7 @@ extern "C"
 		else
 		{
 			GPLE_HIP(ctx, kstar.get(predict_scratch_doubles(a, &chunk_rows, &few_rows)));
-			GPLE_HIP(ctx, launch_predict_q(ctx, st, a, kstar.p, chunk_rows, few_rows));
+			late_contraction = true;
 		}
 		const double* lab_dev = labels;
 		if (labels && small_host)
@@ -1371,6 +1371,12 @@ extern "C"
 				d_cut = o_cut.p;
 			}
 		}
+		if (late_contraction)
+		{
+			// (the output buffers are known by now: a kernel that holds a row's mean and q together may write the outputs itself — predict_fused256_kernel)
+			if (!cplx && !labels && !want_deriv) a.fin_sdev = f->sdev, a.fin_self = f->self, a.fin_mean = d_mean, a.fin_var = d_var, a.fin_cut = d_cut;
+			GPLE_HIP(ctx, launch_predict_q(ctx, st, a, kstar.p, chunk_rows, few_rows, &finished));
+		}
 		const int nblk = (Mi + 255) / 256;
 		double* err_part = nullptr;
 		if (labels)
@@ -1378,7 +1384,8 @@ extern "C"
 			GPLE_HIP(ctx, epart.get(nblk + 1));
 			err_part = epart.p;
 		}
-		if (cplx)
+		if (finished) {}
+		else if (cplx)
 			GPLE_HIP(ctx, launch_predict_finish_complex(st, q.p, mu.p, Mi, Mh, f->self, f->sdev, lab_dev, d_mean, d_var, d_cut, err_part));
 		else
 			GPLE_HIP(ctx, launch_predict_finish_real(st, q.p, mu.p, Mi, f->self, f->sdev, lab_dev, d_mean, d_var, d_cut, err_part));

@@ -225,14 +225,6 @@ namespace gple
 			}
 		}
 
-		// kernel.h:301-332
-		__device__ __forceinline__ double cutoff_value(double pred_square, double abs_pred, double var)
-		{
-			if (pred_square >= 4.0 * var) return 1.0;
-			if (pred_square <= var) return 0.0;
-			const double a = abs_pred / sqrt(var);
-			return (3.0 * 2.0 - 2.0 * a - 1.0) * ((a - 1.0) * (a - 1.0)) / 1.0;
-		}
 		// complex_kernel.cpp:648-668: result[ip] = 2 Re( PredictionDifference^H (dK* v + K* dv + dK~* conj(v) + K~* conj(dv)) )
 		// = 2 sum_i (diff_x z_x + diff_y z_y) with z = dc_ip w + c dw_ip in the [Re; Im] basis
 		__global__ void __launch_bounds__(256) predict_deriv_finish_complex_kernel(const double* __restrict__ acc, int m_rows, int m_split,

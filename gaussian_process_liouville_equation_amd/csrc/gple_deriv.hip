@@ -119,14 +119,6 @@ namespace gple
 			}
 		}
 
-		// kernel.h:301-332
-		__device__ __forceinline__ double cutoff_value(double pred_square, double abs_pred, double var)
-		{
-			if (pred_square >= 4.0 * var) return 1.0;
-			if (pred_square <= var) return 0.0;
-			const double a = abs_pred / sqrt(var);
-			return (3.0 * 2.0 - 2.0 * a - 1.0) * ((a - 1.0) * (a - 1.0)) / 1.0;
-		}
 		// result[ip] = 2 * PredictionDifference . (dK*_ip v + K* dv_ip), PredictionDifference = Cutoff * s - s t  (kernel.cpp:527-536)
 		__global__ void __launch_bounds__(256) predict_deriv_finish_real_kernel(const double* __restrict__ acc, int m_rows, const double* __restrict__ q,
 			int M, double self, double sf, const double* __restrict__ s_dev, const double* __restrict__ labels, double* __restrict__ part)

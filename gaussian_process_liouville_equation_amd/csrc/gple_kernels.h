@@ -20,6 +20,17 @@ namespace gple
 		SEParam p[3];
 	};
 
+	// cutoff_factor, kernel.h:301-332: 1 where |pred|^2 >= 4 var, 0 where |pred|^2 <= var, the cubic in between (one definition for every epilogue)
+	__device__ __forceinline__ double cutoff_value(double pred_square, double abs_pred, double var)
+	{
+		if (pred_square >= 4.0 * var) return 1.0;
+		if (pred_square <= var) return 0.0;
+		const double a = abs_pred / sqrt(var);
+		return (3.0 * 2.0 - 2.0 * a - 1.0) * ((a - 1.0) * (a - 1.0)) / 1.0;
+	}
+	// the factorisation's info word in the fit's scalar block (gple_capi.hip, SDEV_INFO): negative = the one-launch scheme gave up, everything derived
+	// from the factor is NaN until the host has repeated it
+	__device__ __forceinline__ bool fit_gave_up(const double* s_dev) { return *reinterpret_cast<const int*>(s_dev + 31) < 0; }
 	// exp(x) for finite x <= 0 (the argument of a squared-exponential kernel), fp64, < 1 ulp:
 	// x = k ln2 + r (Cody-Waite with an FMA), |r| <= ln2/2, degree-12 Taylor/Horner, scaling by v_ldexp_f64 (which
 	// handles the gradual underflow for x < -708).  No special-case branches.
@@ -190,6 +201,11 @@ namespace gple
 		                                 //    |mu|^2 >= cut_thr = 4 k(x*,x*) >= 4 var has factor 1 whatever q is (kernel.h:301-332) and is not contracted
 		double prune_thr;                // > 0: rows with |k*|^2 below it are not contracted (gple_predict.hip, Prune)
 		unsigned long long* prune_stats; // device, 4 words: [0] += ceil(live rows / 128), [1] += rows / 128, [2] work-queue counter, [3] live-row count
+		// PredictiveKernel's epilogue (kernel.cpp:496-522) for a kernel that can do it itself (predict_fused256_kernel): fin_sdev != nullptr offers it,
+		// launch_predict_q says through *finished whether it was taken (q and mu are then not written).  Real GP without labels only.
+		const double* fin_sdev; // the fit's scalar block: [0] the label scale, [31] the factorisation's info word
+		double fin_self;        // k(x*, x*)
+		double *fin_mean, *fin_var, *fin_cut; // M each, nullable
 	};
 	// Rolling K* scratch of the predict path (HBM): bounded so that M x N never has to exist at once.
 	constexpr size_t PREDICT_SCRATCH_BYTES = size_t(4) << 30;
@@ -200,7 +216,7 @@ namespace gple
 	size_t predict_few_scratch_doubles(const PredictArgs& a);
 	hipError_t launch_predict_few(hipStream_t s, const PredictArgs& a, double* scratch);
 	// fills a.q and a.mu; per chunk: kstar_gen_kernel then rownorm_kernel (bracketed by the context's chunk timers)
-	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows, bool few_rows);
+	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows, bool few_rows, bool* finished = nullptr);
 	// real finish: var = self - q, cutoff, cut = mu*cf/s ; optional labels -> err_out[0] += sum (mu - s t)^2
 	hipError_t launch_predict_finish_real(hipStream_t s, const double* q, const double* mu, int M, double self, const double* s_dev,
 		const double* labels, double* mean, double* var, double* cut, double* err_out);

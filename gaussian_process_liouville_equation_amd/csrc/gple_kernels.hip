@@ -305,14 +305,6 @@ namespace gple
 			}
 		}
 
-		// kernel.h:301-332
-		__device__ __forceinline__ double cutoff_value(double pred_square, double abs_pred, double var)
-		{
-			if (pred_square >= 4.0 * var) return 1.0;
-			if (pred_square <= var) return 0.0;
-			const double a = abs_pred / sqrt(var);
-			return (3.0 * 2.0 - 2.0 * a - 1.0) * ((a - 1.0) * (a - 1.0)) / 1.0;
-		}
 		__global__ void __launch_bounds__(256) cutoff_kernel(const double* __restrict__ pred, int is_complex, const double* __restrict__ var, int M,
 			double* __restrict__ factor)
 		{
@@ -330,7 +322,6 @@ namespace gple
 		}
 
 		// the fit's scalar block: [0] rescale factor, [31] info of the factorisation (an int in the double's slot; gple_capi.hip SDEV_INFO)
-		__device__ __forceinline__ bool fit_gave_up(const double* s_dev) { return *reinterpret_cast<const int*>(s_dev + 31) < 0; }
 		// PredictiveKernel epilogue (kernel.cpp:496-522)
 		__global__ void __launch_bounds__(256) predict_finish_real_kernel(const double* __restrict__ q, const double* __restrict__ mu, int M,
 			double self, const double* __restrict__ s_dev, const double* __restrict__ labels, double* __restrict__ mean,

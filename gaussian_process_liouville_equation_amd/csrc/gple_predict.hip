@@ -1063,8 +1063,17 @@ namespace gple
 				for (int c = 0; c < WN; ++c) sum += red[c * TM + t];
 				double qv = 0.0; // the VG planes in order: plane 0 holds the one N-tile, the others are zero
 				qv += sum;
-				a.q[m0 + t] = qv;
-				a.mu[m0 + t] = msum + mu; // (w == 0 for these threads) the last k-range
+				const double m = msum + mu; // (w == 0 for these threads) the last k-range
+				if (a.fin_sdev == nullptr) a.q[m0 + t] = qv, a.mu[m0 + t] = m;
+				else if (m0 + t < a.M)
+				{
+					// predict_finish_real_kernel's lines (kernel.cpp:496-522)
+					const double vv = fit_gave_up(a.fin_sdev) ? __builtin_nan("") : a.fin_self - qv;
+					const double cf = cutoff_value(m * m, fabs(m), vv);
+					if (a.fin_mean) a.fin_mean[m0 + t] = m;
+					if (a.fin_var) a.fin_var[m0 + t] = vv;
+					if (a.fin_cut) a.fin_cut[m0 + t] = m * cf / *a.fin_sdev;
+				}
 			}
 		}
 		__global__ void __launch_bounds__(NTHREADS, 1) predict_fused256_kernel(const PredictArgs a, int ksplit)
@@ -1342,8 +1351,9 @@ namespace gple
 		return hipGetLastError();
 	}
 
-	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows, bool few_rows)
+	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows, bool few_rows, bool* finished)
 	{
+		if (finished) *finished = false;
 		if (a.M <= 0) return hipSuccess;
 		if (a.m_rows % BM || a.n_total % BN || a.m_split % BM || a.n_split % BN || chunk_rows % BM || chunk_rows <= 0)
 			return hipErrorInvalidValue;
@@ -1405,6 +1415,7 @@ namespace gple
 			ctx->last_contraction = "predict_fused256_kernel";
 			hipLaunchKernelGGL(predict_fused256_kernel, dim3(a.m_rows / 64), dim3(NTHREADS), 0, s, a, ksplit);
 			chunk_timer_stop(ctx);
+			if (finished) *finished = a.fin_sdev != nullptr;
 			return hipGetLastError();
 		}
 		// the variance only decides the cut-off factor: points whose mean is large enough for factor 1 whatever the variance are not contracted

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 WL=${1:-C4r}; shift
 TAG=${TAG:-$WL}
-RX="rownorm|kstar_gen"; [ "$WL" = "C4opt" ] && RX="gemm_f64"
+RX="rownorm|kstar_gen|predict_fused"; [ "$WL" = "C4opt" ] && RX="gemm_f64"
 B="python3 $R/bench.py --workload $WL --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$TAG -- $B --steps 5 --warmup 2 > $OUT/stats_$TAG.log 2>&1 || exit 1
 for C in FETCH_SIZE WRITE_SIZE; do

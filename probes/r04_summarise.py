@@ -44,7 +44,7 @@ entry = {"kernel": dom, "fetch_size_kb": fetch, "write_size_kb": write, "hbm_byt
 # algorithmic bytes of one launch
 from bench import WORKLOADS
 N, G, kind = WORKLOADS[wl]
-if kind in ("real", "complex") and dom.startswith("rownorm"):
+if kind in ("real", "complex") and (dom.startswith("rownorm") or dom.startswith("predict_fused")):
     n, rows_total = (2 * N, 2 * G * G) if kind == "complex" else (N, G * G)
     launches = bench.get("roofline", {}).get("launches_per_step") or 1
     m_chunk = rows_total / launches
@@ -54,6 +54,10 @@ if kind in ("real", "complex") and dom.startswith("rownorm"):
     entry["algorithmic_flops_per_launch"] = m_chunk * n * (n + 1)
     entry["note"] = ("K* chunk re-read once per 256-column tile of T it meets, M_chunk * n * 8 * (ntiles + 1) / 2, + the lower triangle of T once "
                      "(the per-workgroup re-reads of T are served by L2 / MALL)")
+    if dom.startswith("predict_fused"):  # K* never exists in memory: the points in, three outputs out, T once
+        entry["algorithmic_bytes_per_launch"] = int(m_chunk * (16 + 24) + n * (n + 1) / 2 * 8)
+        entry["note"] = "test points in (16 B), mean / variance / cut-off out (24 B), the lower triangle of T once; K* is generated in LDS"
+
 elif kind == "opt":
     if tag.endswith("only1"):  # the complex element: two N x 2N x N block products per sub-kernel parameter (csrc/gple_capi.hip, complex_fit_derivatives)
         entry["launch"] = f"E = A M_a or F = B M_b of one sub-kernel parameter: {N} x {2 * N} x {N}"
