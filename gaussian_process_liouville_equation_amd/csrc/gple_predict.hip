@@ -577,10 +577,10 @@ namespace gple
 		// first operand reads of the next step | ~80 scalar instructions of DMA addressing around six LDS-DMA issues | wait for the operands |
 		// MFMAs.  Both waves of a SIMD come out of the barrier together and stay in step, so they reach the scalar stretch together and the
 		// MFMA pipe idles through it and through the LDS latency behind it: ~900 of a step's 8600 cycles at C4r (MFMA pipe busy 89.8 %).
-		// Here the order behind the barrier is pinned (sched_barrier): the next step's first operands are requested FIRST, then the six DMA
-		// issues go out between the MFMAs of the last group, whose operands were read before the barrier — nothing that follows the barrier
-		// waits for anything but the barrier.  The DMA addressing is two SGPR bases per slab and six constant VGPR offsets (saddr form).
-		// A slab is requested TWO steps ahead of its use... no: one step, as before (issued behind the barrier that ends step s - 1, needed
+		// Here the order around the barrier is pinned (sched_barrier): two MFMAs of the last group straddle it (their operands were read before
+		// it), then the next step's first operands are requested, then the six DMA issues go out between the group's other MFMAs — nothing that
+		// follows the barrier waits for anything but the barrier.  The DMA addressing is two SGPR bases per slab and six constant VGPR offsets
+		// (saddr form).  A slab is requested one step ahead of its use, as before (issued behind the barrier that ends step s - 1, needed
 		// behind the barrier that ends step s) — but the sequence of slabs runs across N-tiles and virtual groups: the first slabs of the next
 		// tile are requested during the last steps of the current one, so a tile no longer starts with an exposed DMA round trip (16 per row
 		// block at n = 4096, 4 of 160 steps' worth at n = 1024); only a unit does.  The tiles of the unit are listed in LDS in the order
@@ -680,15 +680,17 @@ namespace gple
 #pragma unroll
 					for (int kk = 4; kk < KB; kk += 4)
 					{
-						// (the order is pinned: hipcc otherwise gathers the reads of all groups in front of the barrier and sinks the MFMAs behind it)
+						// Inside the three groups in front of the barrier hipcc schedules (it requests a group's operands two MFMAs before the end of the
+						// group before: 0.923 of the peak at C4r against 0.911 with the requests pinned to the start of the group, 0.918 in its middle —
+						// same box); what is pinned is the barrier's neighbourhood: unpinned, hipcc gathers the reads of ALL groups in front of the barrier
+						// and sinks three groups of MFMAs behind it
 						read_ops(p, kk, nA, nB);
 						if (kk == 8) advance(__builtin_amdgcn_readfirstlane(next_entry_v));
-						__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 						for (int i = 0; i < AF; ++i)
 #pragma unroll
 							for (int j = TMIN; j < BF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(cB[j], cA[i], acc[i][j], 0, 0, 0);
-						__builtin_amdgcn_sched_barrier(0);
+						if (kk == 12) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 						for (int i = 0; i < AF; ++i) cA[i] = nA[i];
 #pragma unroll
