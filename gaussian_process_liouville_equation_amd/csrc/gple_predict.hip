@@ -1367,7 +1367,10 @@ namespace gple
 			const char* e = getenv("GPLE_ROWNORM_VARIANT");
 			return e ? atoi(e) : -1;
 		}();
-		const int variant = forced >= 0 ? forced : (a.n_total / BN >= 8 ? 2 : 3); // with the LDS-DMA staging the 2 x 8 blocking leads below eight N-tiles (C2: 64.3 vs 62.9 / 61.2 TFLOP/s)
+		// Round 2: with the LDS-DMA staging the 2 x 8 blocking led below eight N-tiles (C2: 64.3 vs 62.9 / 61.2 TFLOP/s).  Round 4, rownormp_kernel: 4 x 4 leads at
+		// C2 too (three same-box pairs: 0.835 / 0.841 / 0.846 of the peak against 0.830 / 0.838 / 0.836); one and two N-tiles stay on 2 x 8, the arithmetic of
+		// rownorm3_kernel and predict_fused256_kernel (the same rows come out bit for bit whichever of the three a call gets)
+		const int variant = forced >= 0 ? forced : (a.n_total / BN >= 3 ? 2 : 3);
 		// short factors with few row blocks (C1): 64-row workgroups with three slabs in flight (rownorm3_kernel; same bits as <2,8>).  GPLE_ROWNORM_SHORT=0: A/B
 		static const bool short_ok = [] {
 			const char* e = getenv("GPLE_ROWNORM_SHORT");
