@@ -16,6 +16,12 @@
 // Fused variants (lock-step, interleaved, wave-specialised ping-pong) all stalled at 52 TFLOP/s at N=4096; the plain
 // lock-step MFMA loop with LDS operand reads sustains 72.6 TFLOP/s on its own.
 //
+// The contraction kernels, oldest first — all on the same 128 x 256 tile, K advancing 16 per barrier, the same virtual-group sums, the newer ones
+// bit-identical to their predecessor with the same blocking: rownorm_kernel (round 1; GPLE_ROWNORM_VARIANT=0), rownorm2_kernel (round 2: 4 x 4 / 2 x 8
+// fragments per wave, slabs by LDS-DMA; GPLE_ROWNORM_PIPE=0), rownormp_kernel (round 4, the default: the k-steps of a unit as one pipeline pinned
+// around the barrier), rownorm3_kernel (n <= 512 with few row blocks) and predict_fused256_kernel (round 4: the whole predict of a real fit with
+// N <= 256 in one launch, K* generated inside).
+//
 // rownorm_kernel: one workgroup = 8 waves owns 128 test rows and loops over 256-wide N-tiles of T; K advances 16 per
 // step through a double-buffered LDS stage (global -> registers -> LDS, loads issued before the MFMAs of the current
 // step).  Every wave owns 16 rows x all 256 columns (16 accumulator tiles), so the all-zero blocks of T (k > n) are
