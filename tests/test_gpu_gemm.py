@@ -67,6 +67,14 @@ CASES = [
     (128, False, False, False, 256, 384, 144, K_FULL, False, 0.0),   # derivative products
     (128, True, True, False, 256, 256, 256, K_GE_MAX_MN, True, 0.0),
     (128, False, True, False, 256, 256, 256, K_LE_M, False, 2.0),
+    # more shapes of the 128-tile kernel (round 4: one and two slabs, k-ranges with row-contiguous operands, lower tiles, the XCD-aware tile order)
+    (128, False, False, True, 256, 128, 208, K_FULL, False, 0.0),
+    (128, False, False, False, 128, 256, 16, K_FULL, False, 1.5),    # one slab
+    (128, False, False, False, 384, 128, 32, K_FULL, False, 0.0),    # two slabs
+    (128, False, False, False, 384, 384, 384, K_LE_M, False, 0.0),   # k-range by row block
+    (128, False, False, False, 384, 384, 384, K_GE_N, False, 0.0),   # k-range from the column block on
+    (128, False, False, False, 512, 512, 96, K_FULL, True, 1.0),     # lower tiles only
+    (128, False, False, False, 1024, 1024, 512, K_FULL, False, 0.0), # the XCD-aware tile order (8 | N-tiles)
 ]
 
 
@@ -98,3 +106,4 @@ def test_gemm_split_k_is_deterministic(gpu):
     r1 = _gemm(gpu, A, B, C, False, True, False, 1.0, 0.0, K_FULL, False, 32)
     r2 = _gemm(gpu, A, B, C, False, True, False, 1.0, 0.0, K_FULL, False, 32)
     assert np.array_equal(r1, r2)
+
