@@ -643,7 +643,8 @@ def test_short_factor_kernel_has_the_bits_of_the_general_one(gpu, N):
 
 
 @pytest.mark.parametrize("N,M,cplx", [(1024, 40000, False), (700, 9000, True), (2300, 9000, False), (4096, 6100, False), (4096, 40000, False), (1500, 20000, True),
-                                          (100, 30000, True), (300, 70000, False), (600, 12000, False)])  # one, two and three N-tiles
+                                          (100, 30000, True), (300, 70000, False), (600, 12000, False),  # one, two and three N-tiles
+                                          (4096, 300000, False)])  # three K* chunks in the full predict, a live-row list that crosses a chunk boundary in the pruned one
 def test_rownorm_variants_agree_bit_for_bit(gpu, N, M, cplx):
     """rownormp_kernel (the k-steps of a unit as one pipeline: operands of the next step requested right behind the barrier, the DMA issues between
     the MFMAs of the last group, slabs requested across tile boundaries) against rownorm2_kernel (barrier-to-barrier k-steps): per accumulator
