@@ -380,6 +380,15 @@ namespace
 		return GPLE_OK;
 	}
 
+	// GPLE_DERIV_BATCH=0: a launch per product in the derivative fits of small matrices too (A/B, and the bits check of the batched path)
+	static bool deriv_batching()
+	{
+		static const bool on = [] {
+			const char* e = getenv("GPLE_DERIV_BATCH");
+			return e == nullptr || atoi(e) != 0;
+		}();
+		return on;
+	}
 	// TrainingKernel derivative members (kernel.cpp:337-477) for the real kernel; raw sums land in sdev[16..28]
 	int real_fit_derivatives(gple_ctx* ctx, FitCommon* f, double sf, double l0, double l1, double sn, unsigned flags)
 	{
@@ -398,6 +407,64 @@ namespace
 		GPLE_HIP(ctx, dwd.get(4 * static_cast<size_t>(nt)));
 		double* dv = f->dv;
 		GPLE_HIP(ctx, launch_deriv_gram(st, f->Xt, f->N, nt, f->ps.p[0], D.p, D.p + n2));
+		if (nt <= 1024 && deriv_batching())
+		{
+			// Small matrices: the same products, batched into a third of the launches (17 -> 8; a derivative fit at N = 256 is 0.1 ms of 4-5 us kernels).
+			// Items of a batch are independent; every item's arithmetic is that of the launch-per-item path below (same bits).
+			const double cn = -2.0 * (sf * sf) * sn;
+			Scratch tv2(ctx), C2(ctx), part3(ctx);
+			GPLE_HIP(ctx, tv2.get(2 * static_cast<size_t>(nt)));
+			GPLE_HIP(ctx, part3.get(3 * static_cast<size_t>(nt / 256) * nt));
+			{
+				const double* x[2] = {f->v, f->w};
+				const double al[2] = {-2.0 / sf, -2.0 / sf};
+				const int nn[2] = {nt, nt};
+				double* y[2] = {dv, dwd.p};
+				GPLE_HIP(ctx, launch_scale_batch(st, 2, x, al, nn, y)); // magnitude: dW = -2 W / sf (:349)
+			}
+			{
+				const double* A[3] = {D.p, D.p + n2, f->W};
+				const double* x[3] = {f->v, f->v, f->v};
+				const double al[3] = {1.0, 1.0, cn};
+				double* y[3] = {tv2.p, tv2.p + nt, dv + 3 * static_cast<size_t>(nt)};
+				GPLE_HIP(ctx, launch_gemv_batch(st, nt, 3, A, nt, x, al, part3.p, y)); // dK_d v; noise: (dW) y = cn W v (:358)
+			}
+			{
+				const double* A[2] = {f->W, f->W};
+				const double* x[2] = {tv2.p, tv2.p + nt};
+				const double al[2] = {-1.0, -1.0};
+				double* y[2] = {dv + static_cast<size_t>(nt), dv + 2 * static_cast<size_t>(nt)};
+				GPLE_HIP(ctx, launch_gemv_batch(st, nt, 2, A, nt, x, al, part3.p, y)); // (dW) y = -W (dK v) (:354)
+			}
+			int act[2], nact = 0;
+			for (int d = 0; d < 2; ++d)
+			{
+				if (f->deriv_mask >> (1 + d) & 1u) act[nact++] = d;
+				else GPLE_HIP(ctx, hipMemsetAsync(dwd.p + static_cast<size_t>(1 + d) * nt, 0, static_cast<size_t>(nt) * sizeof(double), st));
+			}
+			const double* cA[3];
+			const double* cB[3];
+			double cal[3];
+			double* cy[3];
+			int nc = 0;
+			if (nact)
+			{
+				GPLE_HIP(ctx, C2.get(nact * n2));
+				GemmDesc g{};
+				g.A = D.p + act[0] * n2, g.lda = nt, g.strideA = nact == 2 ? static_cast<long>(n2) : 0, g.B = f->W, g.ldb = nt, g.strideB = 0, g.C = C2.p, g.ldc = nt,
+				g.strideC = static_cast<long>(n2);
+				g.M = nt, g.N = nt, g.K = nt, g.batch = nact, g.alpha = 1.0, g.beta = 0.0, g.krange = K_FULL, g.lower_only = 0;
+				g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
+				timer_start(ctx, GPLE_TIMER_DERIV_GEMM);
+				GPLE_HIP(ctx, launch_gemm(st, g, gemm_pick_tile(nt, nt, 1, false))); // (the tile of ONE product: the items must not change kernel, i.e. bits, with the batch)
+				timer_stop(ctx, GPLE_TIMER_DERIV_GEMM);
+				for (int a = 0; a < nact; ++a) cA[nc] = f->W, cB[nc] = C2.p + a * n2, cal[nc] = -1.0, cy[nc] = dwd.p + static_cast<size_t>(1 + act[a]) * nt, ++nc;
+			}
+			cA[nc] = f->W, cB[nc] = f->W, cal[nc] = cn, cy[nc] = dwd.p + 3 * static_cast<size_t>(nt), ++nc;
+			GPLE_HIP(ctx, launch_coldot_batch(st, nt, nc, cA, nt, cB, nt, 0, cal, cy)); // diag(dW)_i = -sum_j W(j,i) (dK W)(j,i); noise: cn sum_j W(j,i)^2
+		}
+		else
+		{
 		// magnitude: dW = -2 W / sf (:349)
 		GPLE_HIP(ctx, launch_scale(st, f->v, -2.0 / sf, nt, dv));
 		GPLE_HIP(ctx, launch_scale(st, f->w, -2.0 / sf, nt, dwd.p));
@@ -425,6 +492,7 @@ namespace
 		const double cn = -2.0 * (sf * sf) * sn;
 		GPLE_HIP(ctx, launch_gemv(st, f->W, nt, nt, f->v, cn, part.p, dv + 3 * static_cast<size_t>(nt)));
 		GPLE_HIP(ctx, launch_coldot(st, f->W, nt, f->W, nt, nt, 0, cn, dwd.p + 3 * static_cast<size_t>(nt)));
+		}
 		GPLE_HIP(ctx, launch_real_deriv_sums(st, f->v, f->w, dv, dwd.p, f->N, nt, f->sdev + 16));
 		if (flags & GPLE_CALC_AVERAGE)
 		{

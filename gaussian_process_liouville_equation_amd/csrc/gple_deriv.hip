@@ -71,6 +71,85 @@ namespace gple
 			for (int k = 0; k < 256; ++k) acc = fma(a[static_cast<long>(k) * lda], xs[k], acc);
 			part[static_cast<long>(kc) * n + i] = acc;
 		}
+		// The same product for small matrices (n <= 1024): gemv_partial_kernel gives a 256-row block ONE workgroup per 256 columns, every thread a chain of
+		// 256 dependent loads and FMAs — 13 us for the 256 x 256 product of the objective's gradient at the size the reference runs, on one CU of 256.
+		// Here a workgroup takes 64 rows, its four waves a quarter of the 256-column chunk each (chains of 64), the quarters meet in LDS in a fixed order;
+		// with one chunk (n = 256) the result is written at once and there is no second kernel.
+		__global__ void __launch_bounds__(256) gemv_small_kernel(const double* __restrict__ A, long lda, int n, const double* __restrict__ x, double alpha,
+			double* __restrict__ part, double* __restrict__ y)
+		{
+			__shared__ double xs[256];
+			__shared__ double red[4][64];
+			const int kc = blockIdx.y, r = threadIdx.x & 63, sl = threadIdx.x >> 6;
+			xs[threadIdx.x] = x[kc * 256 + threadIdx.x];
+			__syncthreads();
+			const int i = blockIdx.x * 64 + r;
+			const double* __restrict__ a = A + i + (static_cast<long>(kc) * 256 + sl * 64) * lda;
+			double acc = 0.0;
+#pragma unroll 16
+			for (int k = 0; k < 64; ++k) acc = fma(a[static_cast<long>(k) * lda], xs[sl * 64 + k], acc);
+			red[sl][r] = acc;
+			__syncthreads();
+			if (sl == 0)
+			{
+				const double v = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+				if (gridDim.y == 1) y[i] = alpha * v;
+				else part[static_cast<long>(kc) * n + i] = v;
+			}
+		}
+		// Up to three of these products / column dots / scalings in one launch (blockIdx.z picks the item): at the sizes the reference runs a derivative
+		// fit is a string of 4-5 us launches, and the items of a batch do not depend on each other (launch_*_batch; the arithmetic per item is unchanged)
+		struct Batch3
+		{
+			const double* A[3];
+			const double* x[3]; // gemv: the vector; coldot: the second matrix; scale: unused
+			double alpha[3];
+			double* y[3];
+		};
+		__global__ void __launch_bounds__(256) gemv_small_batch_kernel(const Batch3 b, long lda, int n, double* __restrict__ part)
+		{
+			__shared__ double xs[256];
+			__shared__ double red[4][64];
+			const int z = blockIdx.z, kc = blockIdx.y, r = threadIdx.x & 63, sl = threadIdx.x >> 6;
+			xs[threadIdx.x] = b.x[z][kc * 256 + threadIdx.x];
+			__syncthreads();
+			const int i = blockIdx.x * 64 + r;
+			const double* __restrict__ a = b.A[z] + i + (static_cast<long>(kc) * 256 + sl * 64) * lda;
+			double acc = 0.0;
+#pragma unroll 16
+			for (int k = 0; k < 64; ++k) acc = fma(a[static_cast<long>(k) * lda], xs[sl * 64 + k], acc);
+			red[sl][r] = acc;
+			__syncthreads();
+			if (sl == 0)
+			{
+				const double v = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+				if (gridDim.y == 1) b.y[z][i] = b.alpha[z] * v;
+				else part[(static_cast<long>(z) * gridDim.y + kc) * n + i] = v;
+			}
+		}
+		__global__ void __launch_bounds__(256) gemv_reduce_batch_kernel(const Batch3 b, const double* __restrict__ part, int n)
+		{
+			const int z = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x, nc = n / 256;
+			double acc = 0.0;
+			for (int kc = 0; kc < nc; ++kc) acc += part[(static_cast<long>(z) * nc + kc) * n + i];
+			b.y[z][i] = b.alpha[z] * acc;
+		}
+		__global__ void __launch_bounds__(256) coldot_batch_kernel(const Batch3 b, long lda, long ldb, int n, int shift)
+		{
+			const int z = blockIdx.z, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+			if (i + shift >= n) return;
+			const double* __restrict__ a = b.A[z] + static_cast<long>(i) * lda;
+			const double* __restrict__ c = b.x[z] + static_cast<long>(i + shift) * ldb;
+			double acc = 0.0;
+			for (int j = lane; j < n; j += 64) acc = fma(a[j], c[j], acc);
+			acc = wave_sum(acc);
+			if (lane == 0) b.y[z][i] = b.alpha[z] * acc;
+		}
+		__global__ void __launch_bounds__(256) scale_batch_kernel(const Batch3 b, int n0, int n1, int n2)
+		{
+			const int z = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x, n = z == 0 ? n0 : (z == 1 ? n1 : n2);
+			if (i < n) b.y[z][i] = b.alpha[z] * b.A[z][i];
+		}
 		__global__ void __launch_bounds__(256) gemv_reduce_kernel(const double* __restrict__ part, int n, double alpha, double* __restrict__ y)
 		{
 			const int i = blockIdx.x * 256 + threadIdx.x;
@@ -163,8 +242,43 @@ namespace gple
 	}
 	hipError_t launch_gemv(hipStream_t s, const double* A, long lda, int n, const double* x, double alpha, double* part, double* y)
 	{
+		if (n <= 1024) // few workgroups of long chains otherwise (gemv_small_kernel)
+		{
+			hipLaunchKernelGGL(gemv_small_kernel, dim3(n / 64, n / 256), dim3(256), 0, s, A, lda, n, x, alpha, part, y);
+			if (n > 256) hipLaunchKernelGGL(gemv_reduce_kernel, dim3(n / 256), dim3(256), 0, s, part, n, alpha, y);
+			return hipGetLastError();
+		}
 		hipLaunchKernelGGL(gemv_partial_kernel, dim3(n / 256, n / 256), dim3(256), 0, s, A, lda, n, x, part);
 		hipLaunchKernelGGL(gemv_reduce_kernel, dim3(n / 256), dim3(256), 0, s, part, n, alpha, y);
+		return hipGetLastError();
+	}
+	// cnt <= 3 independent items in one launch; n <= 1024 (the small product kernel); part: cnt * (n / 256) * n doubles
+	hipError_t launch_gemv_batch(hipStream_t s, int n, int cnt, const double* const* A, long lda, const double* const* x, const double* alpha, double* part,
+		double* const* y)
+	{
+		if (cnt < 1 || cnt > 3 || n > 1024 || n % 256) return hipErrorInvalidValue;
+		Batch3 b{};
+		for (int z = 0; z < cnt; ++z) b.A[z] = A[z], b.x[z] = x[z], b.alpha[z] = alpha[z], b.y[z] = y[z];
+		hipLaunchKernelGGL(gemv_small_batch_kernel, dim3(n / 64, n / 256, cnt), dim3(256), 0, s, b, lda, n, part);
+		if (n > 256) hipLaunchKernelGGL(gemv_reduce_batch_kernel, dim3(n / 256, 1, cnt), dim3(256), 0, s, b, part, n);
+		return hipGetLastError();
+	}
+	hipError_t launch_coldot_batch(hipStream_t s, int n, int cnt, const double* const* A, long lda, const double* const* B, long ldb, int shift, const double* alpha,
+		double* const* out)
+	{
+		if (cnt < 1 || cnt > 3) return hipErrorInvalidValue;
+		Batch3 b{};
+		for (int z = 0; z < cnt; ++z) b.A[z] = A[z], b.x[z] = B[z], b.alpha[z] = alpha[z], b.y[z] = out[z];
+		hipLaunchKernelGGL(coldot_batch_kernel, dim3(n / 4, 1, cnt), dim3(256), 0, s, b, lda, ldb, n, shift);
+		return hipGetLastError();
+	}
+	hipError_t launch_scale_batch(hipStream_t s, int cnt, const double* const* x, const double* alpha, const int* n, double* const* y)
+	{
+		if (cnt < 1 || cnt > 3) return hipErrorInvalidValue;
+		Batch3 b{};
+		int nn[3] = {0, 0, 0}, nmax = 0;
+		for (int z = 0; z < cnt; ++z) b.A[z] = x[z], b.alpha[z] = alpha[z], b.y[z] = y[z], nn[z] = n[z], nmax = n[z] > nmax ? n[z] : nmax;
+		hipLaunchKernelGGL(scale_batch_kernel, dim3((nmax + 255) / 256, 1, cnt), dim3(256), 0, s, b, nn[0], nn[1], nn[2]);
 		return hipGetLastError();
 	}
 	hipError_t launch_coldot(hipStream_t s, const double* A, long lda, const double* B, long ldb, int n, int shift, double alpha, double* out)

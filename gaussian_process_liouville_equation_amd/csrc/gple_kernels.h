@@ -131,6 +131,12 @@ namespace gple
 	hipError_t launch_coldot(hipStream_t s, const double* A, long lda, const double* B, long ldb, int n, int shift, double alpha,
 		double* out);
 	hipError_t launch_scale(hipStream_t s, const double* x, double alpha, int n, double* y);
+	// up to three independent items of the above in ONE launch (small matrices: a derivative fit at the sizes the reference runs is a string of 4-5 us launches)
+	hipError_t launch_gemv_batch(hipStream_t s, int n, int cnt, const double* const* A, long lda, const double* const* x, const double* alpha, double* part,
+		double* const* y); // n <= 1024; part: cnt * (n / 256) * n doubles
+	hipError_t launch_coldot_batch(hipStream_t s, int n, int cnt, const double* const* A, long lda, const double* const* B, long ldb, int shift, const double* alpha,
+		double* const* out);
+	hipError_t launch_scale_batch(hipStream_t s, int cnt, const double* const* x, const double* alpha, const int* n, double* const* y);
 	// raw sums of the real derivative path: out[ip] = error derivative (kernel.cpp:381-400), out[4 + ip] = sum_i dv[ip][i]
 	hipError_t launch_real_deriv_sums(hipStream_t s, const double* v, const double* w, const double* dv, const double* dwd, int N, int ld,
 		double* out);

@@ -1247,7 +1247,18 @@ namespace gple
 			if (i >= m_rows) return;
 			const double* __restrict__ p = mu_part + static_cast<long>(blockIdx.y) * ksplit * m_rows;
 			double s = 0.0;
-			for (int ky = 0; ky < ksplit; ++ky) s += p[static_cast<long>(ky) * m_rows + i];
+			// the planes are added in order; eight loads are in flight at a time (one after the other this loop was a chain of ksplit memory latencies:
+			// 17 us for the 64 planes of a few-rows predict — the extra-point sets of the objective at small N)
+			int ky = 0;
+			for (; ky + 8 <= ksplit; ky += 8)
+			{
+				double v[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) v[u] = p[static_cast<long>(ky + u) * m_rows + i];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) s += v[u];
+			}
+			for (; ky < ksplit; ++ky) s += p[static_cast<long>(ky) * m_rows + i];
 			out[static_cast<long>(blockIdx.y) * m_rows + i] = s;
 		}
 		// q[m] = sum_n Z(n, m)^2 (column m of the n x rows matrix Z = T K*^T): one workgroup per test row

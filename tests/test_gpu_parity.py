@@ -718,6 +718,44 @@ def test_fused_small_predict_has_the_bits_of_the_unfused_path(gpu, oracle, N, M)
     fit.release()
 
 
+def test_batched_derivative_launches_have_the_bits_of_the_launch_per_product_path():
+    """Derivative fits of small matrices (n <= 1024) batch their independent matrix-vector products, column dots and GEMMs into a third of the launches
+    (csrc/gple_capi.hip, real_fit_derivatives / complex_fit_derivatives); every item keeps its arithmetic, so every derivative member must agree bit for bit
+    with the launch-per-product path (GPLE_DERIV_BATCH=0; the switch is read once per process: two child processes)"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from tests.conftest import ROOT
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import gaussian_process_liouville_equation_amd as pkg
+from gaussian_process_liouville_equation_amd import _capi as c
+from tests.test_gpu_configs import config_inputs, THETA_R, THETA_C
+api = pkg.open_api(0)
+out = []
+for N in (100, 256, 300, 700):
+    for cplx in (False, True):
+        X, y, _, _ = config_inputs(N, 8, 11, cplx=cplx)
+        fit = (api.complex_fit if cplx else api.real_fit)(THETA_C if cplx else THETA_R, X, y, 7)
+        sc = fit.scalars
+        out += [np.atleast_1d(np.asarray(sc[k], dtype=float)).ravel() for k in sorted(sc) if "derivative" in k]
+        out.append(np.asarray(fit.get(c.C_INVLBL_DERIV if cplx else c.R_INVLBL_DERIV)).view(float).ravel())
+        fit.release()
+np.save(sys.argv[1], np.concatenate(out))
+api.close()
+""" % ROOT
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for batch in ("0", "1"):
+            f = os.path.join(d, f"d{batch}.npy")
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=dict(os.environ, GPLE_DERIV_BATCH=batch), cwd=ROOT, timeout=600)
+            res.append(np.load(f))
+    assert res[0].shape == res[1].shape and len(res[0]) > 1000 and np.isfinite(res[0]).all()
+    assert np.array_equal(res[0], res[1]), np.abs(res[0] - res[1]).max()
+
+
 def test_forced_128_tiles_on_odd_fork_points_stay_off_unwritten_blocks():
     """the block-row inverse runs its triangular GEMMs on sub-matrices whose origin is a fork point — a multiple of 64 only.  A
     128-tile with a triangular k-range starts at its 128-aligned diagonal tile and would take in a block above the diagonal that nobody writes
