@@ -576,6 +576,56 @@ namespace
 		GPLE_HIP(ctx, dwd.get(8 * static_cast<size_t>(nt)));
 		GPLE_HIP(ctx, dwx.get(8 * static_cast<size_t>(Np)));
 		double* dw = f->dv;
+		if (nt <= 1024 && deriv_batching() && (f->deriv_mask & 0x7eu) == 0x7eu)
+		{
+			// Small matrices, every parameter formed here: the launch-per-product sequence below with its independent products batched (55 -> 25 launches;
+			// a complex derivative fit at N = 256 is 0.3 ms of 4-5 us kernels).  Every item keeps its arithmetic (same bits).
+			Scratch D6(ctx), tv6(ctx), part3(ctx), EF(ctx);
+			const size_t ef = 2 * static_cast<size_t>(Np) * nt; // [E | F] of one parameter
+			GPLE_HIP(ctx, D6.get(6 * n2));
+			GPLE_HIP(ctx, tv6.get(6 * static_cast<size_t>(nt)));
+			GPLE_HIP(ctx, part3.get(3 * static_cast<size_t>(nt / 256) * nt));
+			GPLE_HIP(ctx, EF.get(6 * ef));
+			{
+				const double* x[3] = {f->v, f->w, f->wx};
+				const double al[3] = {-2.0 / s0, -2.0 / s0, -2.0 / s0};
+				const int nn[3] = {nt, nt, Np};
+				double* y[3] = {dw, dwd.p, dwx.p};
+				GPLE_HIP(ctx, launch_scale_batch(st, 3, x, al, nn, y)); // global magnitude: dM = -2 M / s
+			}
+			GPLE_HIP(ctx, launch_gemv(st, f->W, nt, nt, f->v, -sn, part.p, dw + 7 * static_cast<size_t>(nt))); // noise: dM = -sn M M
+			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, f->W, nt, nt, 0, -sn, dwd.p + 7 * static_cast<size_t>(nt)));
+			GPLE_HIP(ctx, launch_coldot(st, f->W, nt, f->W, nt, nt, Np, -sn, dwx.p + 7 * static_cast<size_t>(Np)));
+			for (int ip = 1; ip <= 6; ++ip) GPLE_HIP(ctx, launch_typed_deriv_gram(st, f->Xt, f->N, Np, nt, f->dspec[ip - 1], D6.p + (ip - 1) * n2));
+			for (int grp = 0; grp < 2; ++grp) // parameters 1..3 (R kernel), 4..6 (I kernel)
+			{
+				const double *A[3], *x[3];
+				double al[3];
+				double* y[3];
+				for (int z = 0; z < 3; ++z) A[z] = D6.p + (3 * grp + z) * n2, x[z] = f->v, al[z] = 1.0, y[z] = tv6.p + static_cast<size_t>(3 * grp + z) * nt;
+				GPLE_HIP(ctx, launch_gemv_batch(st, nt, 3, A, nt, x, al, part3.p, y));
+				for (int z = 0; z < 3; ++z) A[z] = f->W, x[z] = tv6.p + static_cast<size_t>(3 * grp + z) * nt, al[z] = -1.0, y[z] = dw + static_cast<size_t>(1 + 3 * grp + z) * nt;
+				GPLE_HIP(ctx, launch_gemv_batch(st, nt, 3, A, nt, x, al, part3.p, y));
+				// E = A M_a, F = B M_b of the three parameters (the comment at the launch-per-product path below)
+				const long ao = grp == 0 ? 0 : Np, bo = grp == 0 ? Np : 0;
+				double* E = EF.p + 3 * grp * ef;
+				GemmDesc g{};
+				g.lda = nt, g.strideA = static_cast<long>(n2), g.B = f->W + ao * static_cast<long>(nt), g.ldb = nt, g.strideB = 0, g.C = E, g.ldc = Np, g.strideC = static_cast<long>(ef);
+				g.A = D6.p + 3 * grp * n2 + ao + ao * static_cast<long>(nt);
+				g.M = Np, g.N = nt, g.K = Np, g.batch = 3, g.alpha = 1.0, g.beta = 0.0, g.krange = K_FULL, g.lower_only = 0;
+				g.a_kmajor = false, g.b_kmajor = false, g.c_trans = false;
+				timer_start(ctx, GPLE_TIMER_DERIV_GEMM);
+				GPLE_HIP(ctx, launch_gemm(st, g, gemm_pick_tile(Np, nt, 1, false))); // (the tile of ONE product: an item's kernel must not depend on the batch)
+				g.A = D6.p + 3 * grp * n2 + ao + bo * static_cast<long>(nt);
+				g.B = f->W + bo * static_cast<long>(nt), g.C = E + static_cast<size_t>(Np) * nt;
+				GPLE_HIP(ctx, launch_gemm(st, g, gemm_pick_tile(Np, nt, 1, false)));
+				timer_stop(ctx, GPLE_TIMER_DERIV_GEMM);
+				GPLE_HIP(ctx, launch_cderiv_diag_batch(st, 3, f->W, nt, static_cast<int>(ao), E, E + static_cast<size_t>(Np) * nt, Np, Np, nt, -1.0,
+					dwd.p + static_cast<size_t>(1 + 3 * grp) * nt, dwx.p + static_cast<size_t>(1 + 3 * grp) * Np, static_cast<long>(ef), nt, Np));
+			}
+		}
+		else
+		{
 		// global magnitude: dC = 2 C / s  ->  dM = -2 M / s
 		GPLE_HIP(ctx, launch_scale(st, f->v, -2.0 / s0, nt, dw));
 		GPLE_HIP(ctx, launch_scale(st, f->w, -2.0 / s0, nt, dwd.p));
@@ -617,6 +667,7 @@ namespace
 			timer_stop(ctx, GPLE_TIMER_DERIV_GEMM);
 			GPLE_HIP(ctx, launch_cderiv_diag(st, f->W, nt, static_cast<int>(ao), E, F, Np, Np, nt, -1.0, dwd.p + static_cast<size_t>(ip) * nt,
 				dwx.p + static_cast<size_t>(ip) * Np));
+		}
 		}
 		GPLE_HIP(ctx, launch_complex_deriv_sums(st, f->v, f->w, f->wx, dw, dwd.p, dwx.p, f->N, Np, f->sdev + 32));
 		if (flags & GPLE_CALC_AVERAGE)

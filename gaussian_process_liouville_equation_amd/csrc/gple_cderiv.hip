@@ -260,11 +260,14 @@ namespace gple
 	namespace
 	{
 		// one wave per column i: three column dots over the Np rows of M_a
+		// (blockIdx.z: one parameter of a batch — E, F and the outputs advance by their strides; a single parameter has gridDim.z = 1)
 		__global__ void __launch_bounds__(256) cderiv_diag_kernel(const double* __restrict__ M, long ldm, int roff, const double* __restrict__ E,
-			const double* __restrict__ F, long lde, int Np, int n, double alpha, double* __restrict__ out_diag, double* __restrict__ out_off)
+			const double* __restrict__ F, long lde, int Np, int n, double alpha, double* __restrict__ out_diag, double* __restrict__ out_off, long ef_stride,
+			long diag_stride, long off_stride)
 		{
 			const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 			if (i >= n) return;
+			E += blockIdx.z * ef_stride, F += blockIdx.z * ef_stride, out_diag += blockIdx.z * diag_stride, out_off += blockIdx.z * off_stride;
 			const double* __restrict__ mi = M + roff + static_cast<long>(i) * ldm;
 			const double* __restrict__ ei = E + static_cast<long>(i) * lde;
 			const double* __restrict__ fi = F + static_cast<long>(i) * lde;
@@ -296,7 +299,14 @@ namespace gple
 	hipError_t launch_cderiv_diag(hipStream_t s, const double* M, long ldm, int roff, const double* E, const double* F, long lde, int Np, int n, double alpha,
 		double* out_diag, double* out_off)
 	{
-		hipLaunchKernelGGL(cderiv_diag_kernel, dim3((n + 3) / 4), dim3(256), 0, s, M, ldm, roff, E, F, lde, Np, n, alpha, out_diag, out_off);
+		hipLaunchKernelGGL(cderiv_diag_kernel, dim3((n + 3) / 4), dim3(256), 0, s, M, ldm, roff, E, F, lde, Np, n, alpha, out_diag, out_off, 0L, 0L, 0L);
+		return hipGetLastError();
+	}
+	hipError_t launch_cderiv_diag_batch(hipStream_t s, int cnt, const double* M, long ldm, int roff, const double* E, const double* F, long lde, int Np, int n,
+		double alpha, double* out_diag, double* out_off, long ef_stride, long diag_stride, long off_stride)
+	{
+		hipLaunchKernelGGL(cderiv_diag_kernel, dim3((n + 3) / 4, 1, cnt), dim3(256), 0, s, M, ldm, roff, E, F, lde, Np, n, alpha, out_diag, out_off, ef_stride,
+			diag_stride, off_stride);
 		return hipGetLastError();
 	}
 	hipError_t launch_typed_deriv_gram(hipStream_t s, const double* Xt, int N, int Np, int n, DSpecSet spec, double* D)

@@ -107,6 +107,9 @@ namespace gple
 	// out_diag (n) and out_off (Np) receive alpha times these: half the flops of the full product dC M.
 	hipError_t launch_cderiv_diag(hipStream_t s, const double* M, long ldm, int roff, const double* E, const double* F, long lde, int Np, int n, double alpha,
 		double* out_diag, double* out_off);
+	// cnt parameters that share roff in one launch: E, F advance by ef_stride per parameter, the outputs by diag_stride / off_stride
+	hipError_t launch_cderiv_diag_batch(hipStream_t s, int cnt, const double* M, long ldm, int roff, const double* E, const double* F, long lde, int Np, int n,
+		double alpha, double* out_diag, double* out_off, long ef_stride, long diag_stride, long off_stride);
 	// out[ip] (ip = 0..7) = TrainingComplexKernel::ErrorDerivatives (complex_kernel.cpp:444-474) from the embedded quantities:
 	// w (weights, n), wd (diag M, n), wx (diag of the Re-Im block, Np) and their derivatives dw (8 x n), dwd (8 x n), dwx (8 x Np)
 	hipError_t launch_complex_deriv_sums(hipStream_t s, const double* w, const double* wd, const double* wx, const double* dw, const double* dwd,
