@@ -12,6 +12,6 @@ for e in 0/2 0/4 0/8 3/8; do
   timeout -k 10 300 python bench.py --via capi --emulate-rank $e --no-cpu-baseline --steps 20 --warmup 3 > gpurun_out/r04_bench/emu_${e/\//_}.json 2>/dev/null || exit 1
 done
 timeout -k 10 300 python bench.py --workload C4 --via capi --comm-at-one --no-cpu-baseline --steps 5 --warmup 1 > gpurun_out/r04_bench/C4.json 2>/dev/null || exit 1
-timeout -k 10 300 python bench.py --workload C2step --steps 5 --warmup 1 > gpurun_out/r04_bench/C2step.json 2>/dev/null || exit 1
+timeout -k 10 300 python bench.py --workload C2step --steps 20 --warmup 3 > gpurun_out/r04_bench/C2step.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --workload C5step --steps 2 --warmup 1 > gpurun_out/r04_bench/C5step.json 2>/dev/null || exit 1
 echo evidence2-done
