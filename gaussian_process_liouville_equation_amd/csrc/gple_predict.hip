@@ -177,6 +177,13 @@ namespace gple
 			const int* n_live; // device: number of live rows (the compacted list's length)
 			int row0;          // offset of this chunk in the compacted list
 			int nblocks, G;    // row blocks of the chunk (upper bound: the live ones are the first ceil((n_live - row0) / 128)), tile groups
+			// A contraction in two launches (rownormp_kernel only; launch_predict_overlapped): the N-tiles [jt_lo, jt_hi) of every unit (jt_hi = 0: all of them).
+			// A virtual group's sum runs over tiles of both launches, lane by lane, before anything is reduced — so the first launch SAVES the per-lane
+			// partial sums of every group (state_mode 1: [row block][VG][wave][fragment][lane], nothing is written to q) and the second STARTS from them
+			// (state_mode 2; a group has saved sums iff it owns a tile below jt_lo, i.e. iff vg < jt_lo): the bits of the unsplit launch.
+			int jt_lo = 0, jt_hi = 0;
+			double* state = nullptr;
+			int state_mode = 0;
 		};
 		// the unit this workgroup works on next: false when there is none (queue mode: the counter ran past the last unit;
 		// static mode: the one unit of the workgroup is done)
@@ -595,7 +602,7 @@ namespace gple
 		constexpr int TL_MAX = 256; // N-tiles of a factor (n <= 65536)
 		template <int AF, int BF, int WNI>
 		__device__ __forceinline__ void rownormp_unit(const double* __restrict__ Ks, int rows, const double* __restrict__ T, long ldt, double* lds,
-			const int* tl, int ntl, double* __restrict__ q, long qstride, int m0, int wm)
+			const int* tl, int ntl, double* __restrict__ q, long qstride, int m0, int wm, double* __restrict__ su, int mode, int jlo)
 		{
 			constexpr int KB = 16, WN = 16 / BF, ASr = BM + 16;
 			constexpr int ASL = KB * ASr, BSL = KB * BS;
@@ -661,9 +668,14 @@ namespace gple
 				for (int j = 0; j < BF; ++j) bf[j] = pb[(kk + fk) * BS + j * (16 * WN)];
 			};
 			read_ops(0, 0, cA, cB);
+			// su: this unit's saved per-lane sums (Prune::state), entry (vg, wave, fragment, lane)
+			auto su_at = [&](int vg, int i) { return su + ((static_cast<long>(vg) * 8 + w) * AF + i) * 64 + lane; };
 			double rsq[AF];
+			{
+				const int vg0 = tile_vg(0);
 #pragma unroll
-			for (int i = 0; i < AF; ++i) rsq[i] = 0.0;
+				for (int i = 0; i < AF; ++i) rsq[i] = (mode == 2 && vg0 < jlo) ? *su_at(vg0, i) : 0.0;
+			}
 			for (int ti = 0; ti < ntl; ++ti)
 			{
 				const int n0 = tile_n0(ti) * BN, vg = tile_vg(ti);
@@ -757,24 +769,33 @@ namespace gple
 				// the last tile of a virtual group: its plane of partial sums (the WN column groups meet in LDS, beside the stage)
 				if (ti + 1 == ntl || tile_vg(ti + 1) != vg)
 				{
-#pragma unroll
-					for (int i = 0; i < AF; ++i)
+					const int vgn = ti + 1 < ntl ? tile_vg(ti + 1) : VG; // the next group of this unit
+					if (mode == 1) // the early tiles: the group's sums wait, lane by lane, for its late tiles
 					{
-						double v = rsq[i];
-						v += __shfl_xor(v, 16);
-						v += __shfl_xor(v, 32);
-						if (lane < 16) red[WNI * BM + wm * (16 * AF) + 16 * i + lane] = v;
-						rsq[i] = 0.0;
-					}
-					__syncthreads();
-					if (threadIdx.x < BM)
-					{
-						double v = 0.0;
 #pragma unroll
-						for (int c = 0; c < WN; ++c) v += red[c * BM + threadIdx.x];
-						q[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = v;
+						for (int i = 0; i < AF; ++i) *su_at(vg, i) = rsq[i], rsq[i] = 0.0;
 					}
-					__syncthreads();
+					else
+					{
+#pragma unroll
+						for (int i = 0; i < AF; ++i)
+						{
+							double v = rsq[i];
+							v += __shfl_xor(v, 16);
+							v += __shfl_xor(v, 32);
+							if (lane < 16) red[WNI * BM + wm * (16 * AF) + 16 * i + lane] = v;
+							rsq[i] = (mode == 2 && vgn < jlo) ? *su_at(vgn, i) : 0.0;
+						}
+						__syncthreads();
+						if (threadIdx.x < BM)
+						{
+							double v = 0.0;
+#pragma unroll
+							for (int c = 0; c < WN; ++c) v += red[c * BM + threadIdx.x];
+							q[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = v;
+						}
+						__syncthreads();
+					}
 				}
 			}
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the two requests past the end
@@ -795,6 +816,7 @@ namespace gple
 			const int simd = w & 3, half = w >> 2;
 			const int wm = WN == 4 ? half : simd, wn = WN == 4 ? (half ? 3 - simd : simd) : (half ^ (simd & 1));
 			const int ntiles = n_total / BN;
+			const int jlo = pr.jt_lo, jhi = pr.jt_hi > 0 ? pr.jt_hi : ntiles; // the N-tiles of this launch
 			int mblock, g, G;
 			for (int it = 0; next_unit<QUEUE>(pr, it, mblock, g, G); ++it)
 			{
@@ -807,29 +829,59 @@ namespace gple
 					for (int vg = 0; vg < VG; ++vg)
 					{
 						if (snake(vg, G) != g) continue;
-						for (int jt = 0; jt < ntiles; ++jt)
+						for (int jt = jlo; jt < jhi; ++jt)
 							if (snake(jt, VG) == vg) tl[c++] = jt | (vg << 16);
 					}
 					tl[c] = -1, tl[c + 1] = -1;
 					s_ntl = c;
 				}
-				// a virtual group without a tile (n < 2048) still owns its plane of the partial sums
-				for (int vg = ntiles; vg < VG; ++vg)
-					if (snake(vg, G) == g && threadIdx.x < BM) q[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = 0.0;
+				// a virtual group without a tile in this launch still owns its plane of the partial sums: zero (n < 2048: it has no tile at all), or —
+				// the late launch of a split contraction — its saved sums, reduced here.  (The early launch writes no plane.)
+				double* const su = pr.state ? pr.state + static_cast<long>(mblock) * (VG * 8 * AF * 64) : nullptr;
+				for (int vg = 0; vg < VG; ++vg)
+				{
+					if (snake(vg, G) != g) continue; // uniform
+					bool has = false;
+					for (int jt = jlo; jt < jhi; ++jt) has = has || snake(jt, VG) == vg;
+					if (has || pr.state_mode == 1) continue;
+					if (pr.state_mode == 2 && vg < jlo)
+					{
+						double* const red = lds + 2 * KB * ASr + 2 * KB * BS;
+						const int lane = threadIdx.x & 63;
+#pragma unroll
+						for (int i = 0; i < AF; ++i)
+						{
+							double v = su[((static_cast<long>(vg) * 8 + w) * AF + i) * 64 + lane];
+							v += __shfl_xor(v, 16);
+							v += __shfl_xor(v, 32);
+							if (lane < 16) red[wn * BM + wm * (16 * AF) + 16 * i + lane] = v;
+						}
+						__syncthreads();
+						if (threadIdx.x < BM)
+						{
+							double v = 0.0;
+#pragma unroll
+							for (int c = 0; c < WN; ++c) v += red[c * BM + threadIdx.x];
+							q[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = v;
+						}
+						__syncthreads();
+					}
+					else if (threadIdx.x < BM) q[static_cast<long>(vg) * qstride + m0 + threadIdx.x] = 0.0;
+				}
 				__syncthreads();
 				const int ntl = __builtin_amdgcn_readfirstlane(s_ntl);
 				if (ntl == 0) continue; // uniform
 				if constexpr (WN == 4)
 				{
-					if (wn == 0) rownormp_unit<AF, BF, 0>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
-					else if (wn == 1) rownormp_unit<AF, BF, 1>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
-					else if (wn == 2) rownormp_unit<AF, BF, 2>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
-					else rownormp_unit<AF, BF, 3>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
+					if (wn == 0) rownormp_unit<AF, BF, 0>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm, su, pr.state_mode, jlo);
+					else if (wn == 1) rownormp_unit<AF, BF, 1>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm, su, pr.state_mode, jlo);
+					else if (wn == 2) rownormp_unit<AF, BF, 2>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm, su, pr.state_mode, jlo);
+					else rownormp_unit<AF, BF, 3>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm, su, pr.state_mode, jlo);
 				}
 				else
 				{
-					if (wn == 0) rownormp_unit<AF, BF, 0>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
-					else rownormp_unit<AF, BF, 1>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm);
+					if (wn == 0) rownormp_unit<AF, BF, 0>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm, su, pr.state_mode, jlo);
+					else rownormp_unit<AF, BF, 1>(Ks, rows, T, ldt, lds, tl, ntl, q, qstride, m0, wm, su, pr.state_mode, jlo);
 				}
 			}
 		}
