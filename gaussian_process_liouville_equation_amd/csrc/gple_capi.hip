@@ -153,6 +153,15 @@ static void ctx_drop(gple_ctx* ctx)
 		for (hipEvent_t ev : ctx->side_forks) (void)hipEventDestroy(ev);
 		if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
 	}
+	if (ctx->early_stream)
+	{
+		(void)hipStreamSynchronize(ctx->early_stream);
+		(void)hipStreamDestroy(ctx->early_stream);
+		for (hipEvent_t ev : {ctx->early_points, ctx->early_done, ctx->early_free})
+			if (ev) (void)hipEventDestroy(ev);
+		if (ctx->early_buf) (void)hipFree(ctx->early_buf);
+	}
+	if (ctx->fit_early_own) (void)hipEventDestroy(ctx->fit_early_own);
 	if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -241,6 +250,7 @@ struct FitCommon
 	// the factorisation with a launch per panel.  Calls that consumed the fit before that — enqueued, never synchronised — have produced NaN:
 	mutable std::atomic<bool> validated{false}; // the host has seen info >= 0 (or has recovered)
 	mutable std::atomic<int> stale_uses{0};     // predicts enqueued on the not yet validated fit
+	int early_rows = 0; // T(0 .. early_rows, .) is final behind the context's fit_early_event (0: only behind the whole fit)
 	unsigned deriv_mask = 0xFFu; // which parameters' N^3 products a derivative fit forms (bit ip; gple_objective_eval_part splits them over ranks)
 	SEParamSet ps{};
 	double self = 0.0; // k(x*, x*)
@@ -376,6 +386,7 @@ namespace
 		GPLE_HIP(ctx, launch_gram_train(st, f->Xt, f->N, Np, nt, f->ps, Lbuf.p, ldl, f->ys));
 		int* info_dev = reinterpret_cast<int*>(f->sdev + 31);
 		GPLE_HIP(ctx, chol_inverse_factor(ctx, st, Lbuf.p, ldl, nt, f->T, nt, info_dev, work.p, u.p));
+		f->early_rows = ctx->fit_early_rows; // (0 under the launch-per-panel scheme, for one-block matrices, and where the first row block's inverse is a merge tree)
 		GPLE_HIP(ctx, launch_colpass(st, f->T, nt, nt, u.p, f->v, f->w, Np, f->wx, info_dev)); // (a give-up of the factorisation: NaN)
 		return GPLE_OK;
 	}
@@ -1327,6 +1338,8 @@ extern "C"
 	// internal flag of predict_common (never part of the ABI's flag space): enqueue everything, including the D2H copies of
 	// the error scalars, but leave the synchronisation and the scalar read-out to the caller
 	constexpr unsigned PREDICT_NO_SYNC = 0x10000u;
+	// internal: the test points lie in the context's early buffer, written on its early stream (predict_sharded with GPLE_PREDICT_OVERLAP=1)
+	constexpr unsigned PREDICT_XS_EARLY = 0x20000u;
 	static void predict_scalars_from_host(gple_ctx* ctx, bool has_labels, bool want_deriv, bool cplx, gple_predict_scalars* scalars)
 	{
 		if (!scalars) return;
@@ -1492,9 +1505,28 @@ extern "C"
 		}
 		if (late_contraction)
 		{
+			// Beside the fit (GPLE_PREDICT_OVERLAP=1): the fit is still in flight, the first rows of its T are final behind an event it left, the points are
+			// device memory that the early stream may read (the caller's, complete before the fit was enqueued — the extra contract of the switch —
+			// or the shard predict_sharded put into the early buffer)
+			const bool early_xs = flags & PREDICT_XS_EARLY;
+			if ((dev || early_xs) && unvalidated && !labels && !want_deriv && ctx->fit_early_event && predict_overlap_applicable(ctx, a, f->early_rows))
+			{
+				double* xs_early = nullptr;
+				GPLE_HIP(ctx, predict_overlap_prepare(ctx, a, early_xs ? 2 * M : 0, &xs_early));
+				GPLE_HIP(ctx, launch_predict_overlapped(ctx, st, a, early_xs ? 2 * M : 0, f->early_rows, ctx->fit_early_event, early_xs ? ctx->early_points : nullptr));
+			}
+			else
+			{
+			if (early_xs) GPLE_HIP(ctx, hipStreamWaitEvent(st, ctx->early_points, 0)); // (a second pass behind a recovered fit: the points still lie in the early buffer)
 			// (the output buffers are known by now: a kernel that holds a row's mean and q together may write the outputs itself — predict_fused256_kernel)
 			if (!cplx && !labels && !want_deriv) a.fin_sdev = f->sdev, a.fin_self = f->self, a.fin_mean = d_mean, a.fin_var = d_var, a.fin_cut = d_cut;
 			GPLE_HIP(ctx, launch_predict_q(ctx, st, a, kstar.p, chunk_rows, few_rows, &finished));
+			if (early_xs)
+			{
+				GPLE_HIP(ctx, hipEventRecord(ctx->early_free, st));
+				ctx->early_free_pending = true;
+			}
+			}
 		}
 		const int nblk = (Mi + 255) / 256;
 		double* err_part = nullptr;
@@ -2041,6 +2073,8 @@ extern "C"
 		hipStream_t st = ctx->stream;
 		// the points go through device buffers whatever the caller's pointers are: the collective runs on device memory
 		Scratch local(ctx), gathered(ctx), xs_all(ctx), xs(ctx), om(ctx), ov(ctx), oc(ctx);
+		double* xs_shard = nullptr; // this rank's points: pooled (xs) or in the early buffer
+		unsigned xs_flag = 0;
 		{
 			std::lock_guard<std::mutex> lk(ctx->call_mu);
 			GPLE_HIP(ctx, hipSetDevice(ctx->device));
@@ -2056,9 +2090,31 @@ extern "C"
 			}
 			if (n_local)
 			{
-				GPLE_HIP(ctx, xs.get(2 * n_local));
-				hipLaunchKernelGGL(shard_points_kernel, dim3(static_cast<unsigned>((n_local + 255) / 256)), dim3(256), 0, st, all_dev, M, rank, deal, n_local, xs.p);
-				GPLE_HIP(ctx, hipGetLastError());
+				// Beside the fit (GPLE_PREDICT_OVERLAP=1, device pointers): this rank's points are dealt out on the early stream into the early buffer —
+				// the main stream is busy with the fit, and a pooled buffer may still be that fit's workspace
+				bool early = false;
+				if (dev && f && !f->validated.load() && f->early_rows > 0 && ctx->fit_early_event && predict_overlap_enabled())
+				{
+					const int Mh = static_cast<int>(round_up(n_local, 128));
+					PredictArgs pa{};
+					pa.M = static_cast<int>(n_local), pa.m_rows = is_complex ? 2 * Mh : Mh, pa.n_total = f->n_total;
+					if (predict_overlap_applicable(ctx, pa, f->early_rows))
+					{
+						GPLE_HIP(ctx, predict_overlap_prepare(ctx, pa, 2 * n_local, &xs_shard));
+						hipLaunchKernelGGL(shard_points_kernel, dim3(static_cast<unsigned>((n_local + 255) / 256)), dim3(256), 0, ctx->early_stream, all_dev, M, rank, deal, n_local,
+							xs_shard);
+						GPLE_HIP(ctx, hipGetLastError());
+						GPLE_HIP(ctx, hipEventRecord(ctx->early_points, ctx->early_stream));
+						early = true, xs_flag = PREDICT_XS_EARLY;
+					}
+				}
+				if (!early)
+				{
+					GPLE_HIP(ctx, xs.get(2 * n_local));
+					xs_shard = xs.p;
+					hipLaunchKernelGGL(shard_points_kernel, dim3(static_cast<unsigned>((n_local + 255) / 256)), dim3(256), 0, st, all_dev, M, rank, deal, n_local, xs.p);
+					GPLE_HIP(ctx, hipGetLastError());
+				}
 			}
 		}
 		// A rank whose own predict fails still enters the collective (with whatever its buffer holds: the other ranks get their
@@ -2068,7 +2124,7 @@ extern "C"
 		std::string err_local;
 		if (n_local)
 		{
-			rc_local = predict_common(ctx, f, xs.p, n_local, GPLE_IO_DEVICE | (flags & GPLE_PREDICT_FULL), nullptr, local.p, local.p + ow * per,
+			rc_local = predict_common(ctx, f, xs_shard, n_local, GPLE_IO_DEVICE | (flags & GPLE_PREDICT_FULL) | xs_flag, nullptr, local.p, local.p + ow * per,
 				local.p + (ow + 1) * per, nullptr);
 			if (rc_local != GPLE_OK)
 			{
@@ -2837,6 +2893,7 @@ extern "C"
 		return GPLE_OK;
 	}
 	const char* gple_debug_last_contraction_kernel(gple_ctx* ctx) { return ctx ? ctx->last_contraction : ""; }
+	long gple_debug_overlapped_predicts(gple_ctx* ctx) { return ctx ? ctx->overlapped_predicts : 0; }
 	int gple_debug_predict_knobs(gple_ctx* ctx, int rownorm_pipe, int fused_small)
 	{
 		if (!ctx) return GPLE_ERR_BAD_ARG;

@@ -2253,6 +2253,7 @@ namespace gple
 	hipError_t chol_inverse_factor(Ctx* ctx, hipStream_t s, double* A, long lda, int n, double* T, long ldt, int* info, double* work, double* uvec)
 	{
 		if (n % NB) return hipErrorInvalidValue;
+		ctx->fit_early_rows = 0;
 		const std::vector<int>& marks = chol_marks(n);
 		if (marks.empty())
 		{
@@ -2319,7 +2320,21 @@ namespace gple
 			hipEvent_t ev = ctx->side_forks[nfork++];
 			if ((er = hipEventRecord(ev, s)) != hipSuccess) return er;
 			if ((er = hipStreamWaitEvent(side, ev, 0)) != hipSuccess) return er;
-			if (!(use_dag && chol_block_inverse_inside(n, done, j, dag_cuts)) && (er = tree(side, done, j, w_side)) != hipSuccess) return er; // (else: formed by the block's launch)
+			const bool inside = use_dag && chol_block_inverse_inside(n, done, j, dag_cuts);
+			if (!inside && (er = tree(side, done, j, w_side)) != hipSuccess) return er; // (else: formed by the block's launch)
+			// The first row block of T is complete here: T(0 .. j, .) — behind the fork where its launch formed it, behind its merge tree on the side stream
+			// otherwise.  A predict may start on those rows (Ctx::fit_early_*).
+			if (done == 0)
+			{
+				if (inside) ctx->fit_early_event = ev;
+				else
+				{
+					if (!ctx->fit_early_own && (er = hipEventCreateWithFlags(&ctx->fit_early_own, hipEventDisableTiming)) != hipSuccess) return er;
+					if ((er = hipEventRecord(ctx->fit_early_own, side)) != hipSuccess) return er;
+					ctx->fit_early_event = ctx->fit_early_own;
+				}
+				ctx->fit_early_rows = j;
+			}
 			if (done > 0 && (er = t_product(side, done, j)) != hipSuccess) return er;
 			if ((er = w_accumulate(side, done, j)) != hipSuccess) return er;
 			done = j;

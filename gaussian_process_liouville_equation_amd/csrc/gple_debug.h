@@ -46,6 +46,8 @@ extern "C"
 	int gple_debug_predict_knobs(gple_ctx* ctx, int rownorm_pipe, int fused_small);
 	/* Name of the kernel the last predict of this context ran its variance contraction on ("" before the first one; bench.py's roofline label). */
 	const char* gple_debug_last_contraction_kernel(gple_ctx* ctx);
+	/* How many predicts of this context ran their early part beside the fit they followed (GPLE_PREDICT_OVERLAP=1; tests/test_gpu_overlap.py). */
+	long gple_debug_overlapped_predicts(gple_ctx* ctx);
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,18 @@ namespace gple
 		// debug knobs of the factorisation (gple_debug_chol_knobs; the give-up test): scheme of this context's fits (-1: GPLE_CHOL_SCHEME, 0: a launch
 		// per panel, 1: one launch per outer block), polls before a wave of the one-launch scheme gives up, workgroups of its launches (0: defaults)
 		int chol_scheme = -1, dag_poll_limit = 0, dag_blocks = 0;
+		// Part of a predict beside the fit it follows (gple_predict.hip, launch_predict_overlapped; GPLE_PREDICT_OVERLAP=1): the fit leaves behind the event
+		// behind which the first rows of T are final (chol_inverse_factor); the early work runs on a stream and in buffers of its own (the pooled scratch is
+		// ordered by the main stream: a pooled buffer may still be in use by the fit that is running)
+		hipEvent_t fit_early_event = nullptr; // of the LAST fit enqueued on this context (a fork event of the factorisation, or fit_early_own)
+		hipEvent_t fit_early_own = nullptr;   // recorded on the side stream behind the first row block's merge tree
+		int fit_early_rows = 0;               // T(0 .. rows, .) is final behind it (0: nothing is)
+		hipStream_t early_stream = nullptr;
+		hipEvent_t early_points = nullptr, early_done = nullptr, early_free = nullptr; // test points in place / early work done (early stream); buffers free again (main stream)
+		bool early_free_pending = false;
+		long overlapped_predicts = 0; // predicts that ran their early part beside a fit (gple_debug_overlapped_predicts)
+		void* early_buf = nullptr;
+		size_t early_bytes = 0;
 		const char* last_contraction = ""; // the kernel the last large predict's contraction ran on (gple_debug_last_contraction_kernel)
 		int fused_small = -1;  // gple_debug_predict_knobs: -1 = GPLE_PREDICT_FUSED_SMALL's choice, 0 = separate kernels, 1 = predict_fused256_kernel where it applies
 		int rownorm_pipe = -1; // gple_debug_predict_knobs: -1 = GPLE_ROWNORM_PIPE's choice, 0 = rownorm2_kernel, 1 = rownormp_kernel (same bits)

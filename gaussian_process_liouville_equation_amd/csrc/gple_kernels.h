@@ -226,6 +226,12 @@ namespace gple
 	hipError_t launch_predict_few(hipStream_t s, const PredictArgs& a, double* scratch);
 	// fills a.q and a.mu; per chunk: kstar_gen_kernel then rownorm_kernel (bracketed by the context's chunk timers)
 	hipError_t launch_predict_q(Ctx* ctx, hipStream_t s, const PredictArgs& a, double* scratch, int chunk_rows, bool few_rows, bool* finished = nullptr);
+	// part of a predict beside the fit it follows (gple_predict.hip; GPLE_PREDICT_OVERLAP=1): applicable? / stream, events, buffers (*xs: room for the caller's
+	// points, to be written on ctx->early_stream) / the launch (t_early: the event behind which T's first early_rows rows are final)
+	bool predict_overlap_enabled();
+	bool predict_overlap_applicable(const Ctx* ctx, const PredictArgs& a, int early_rows);
+	hipError_t predict_overlap_prepare(Ctx* ctx, const PredictArgs& a, size_t xs_doubles, double** xs);
+	hipError_t launch_predict_overlapped(Ctx* ctx, hipStream_t s, const PredictArgs& a, size_t xs_doubles, int early_rows, hipEvent_t t_early, hipEvent_t points_ready);
 	// real finish: var = self - q, cutoff, cut = mu*cf/s ; optional labels -> err_out[0] += sum (mu - s t)^2
 	hipError_t launch_predict_finish_real(hipStream_t s, const double* q, const double* mu, int M, double self, const double* s_dev,
 		const double* labels, double* mean, double* var, double* cut, double* err_out);

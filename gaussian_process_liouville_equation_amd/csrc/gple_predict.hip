@@ -73,6 +73,7 @@ namespace gple
 			const int r = blockIdx.x * 128 + threadIdx.x; // row inside the chunk
 			int gm = row0 + r;                             // row of the typed test set
 			int type_m = (row0 + blockIdx.x * 128) >= a.m_split; // MODE 0, 1: uniform per block (m_split multiple of 128)
+			// MODE 3: K* of the rows [row0, row0 + rows) and nothing else (a generation beside the fit: its weights do not exist yet)
 			if constexpr (MODE == 2)
 			{
 				const int nl = *n_live;
@@ -113,7 +114,7 @@ namespace gple
 					const double g = exp_nonpos(__dmul_rn(-0.5, fma(d0, d0, __dmul_rn(d1, d1))));
 					const double delta = (xm == xk && pm == pkv) ? n2 : 0.0; // delta_kernel: exact equality, kernel.cpp:26
 					const double val = valid ? __dmul_rn(amp, g + delta) : 0.0;
-					if constexpr (MODE != 2) mu = fma(val, a.v[k], mu);
+					if constexpr (MODE != 2 && MODE != 3) mu = fma(val, a.v[k], mu);
 					if constexpr (MODE == 1) nrm = fma(val, val, nrm);
 					if constexpr (DERIV == 2)
 					{
@@ -144,7 +145,7 @@ namespace gple
 				}
 				out += 4L * rows;
 			}
-			if constexpr (MODE != 2) mu_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = mu;
+			if constexpr (MODE != 2 && MODE != 3) mu_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = mu;
 			if constexpr (MODE == 1) nrm_part[static_cast<long>(blockIdx.y) * a.m_rows + gm] = nrm;
 			if constexpr (DERIV != 0)
 #pragma unroll
@@ -1419,6 +1420,150 @@ namespace gple
 		// a k-slice that owns no chunk of a row block (by >= chunks of the block) still writes its zeros: no stale partials
 		hipLaunchKernelGGL(predict_few_kernel, dim3(nblk, KS), dim3(256), 0, s, a, mt, upart, mupart);
 		hipLaunchKernelGGL(predict_few_reduce_kernel, dim3(mt), dim3(256), 0, s, upart, mupart, KS, a.n_total, a.m_split_few, a.m_split, a.q, a.mu);
+		return hipGetLastError();
+	}
+
+	// ---- part of a predict beside the fit it follows ------------------------------------------------------------------------------------------
+	// The contraction needs T, the fit's last product but for its first rows: T(0 .. early_rows, .) is final at the first fork of the factorisation
+	// (chol_inverse_factor), a third of the way into a fit at n = 4096, and the fit hardly uses the chip from there on (a latency-bound spine, GEMMs
+	// on a side stream).  Here, on a stream of the context's own: K* of the rows (store only: the mean needs v, the fit's LAST product) as soon as
+	// the points are there, then — behind the fork's event — rownormp_kernel over the N-tiles below early_rows as a work queue of FEWER workgroups
+	// than CUs (a contraction workgroup shares its CU with nothing: the CUs it leaves out are the fit's), saving every virtual group's per-lane sums.
+	// On the main stream, behind the fit: the means (the generation pass without the store), then the late tiles on all CUs, starting from the saved
+	// sums: bit for bit the unsplit contraction (Prune::state).  Buffers of its own (the pooled scratch is ordered by the main stream).
+	// GPLE_PREDICT_OVERLAP=1 switches it on; GPLE_PREDICT_OVERLAP_CUS = CUs left to the fit (64).  DEFAULT OFF, because it does not pay: measured on the
+	// per-rank proxy (probes/overlap_sweep.sh, N = 4096, an eighth of the 512 x 512 grid) the step is 9.41 ms in turn and 9.46 ... 17 ms overlapped — the
+	// one-launch factorisation slows by 0.3 - 1.0 ms beside ANY early work (its GEMMs and tile tasks want the CUs the early part holds), which is
+	// more than the early part saves (profiles/r04_notes.md).  Kept as a tested, bit-exact experiment for a fit that tolerates company.
+	namespace
+	{
+		__global__ void set_int2_kernel(int* p, int a, int b) { p[0] = a, p[1] = b; }
+		struct OverlapBuffers
+		{
+			double *Ks, *state, *qpart, *mu_part, *nrm_part, *xs;
+			int* counters; // [0] n_live (= rows: every row is live), [1] the work queue's counter
+			size_t bytes;
+		};
+		OverlapBuffers overlap_layout(char* base, const PredictArgs& a, size_t xs_doubles)
+		{
+			OverlapBuffers b{};
+			const size_t ksplit = gen_ksplit(a.m_rows), nblk = a.m_rows / BM;
+			size_t off = 0;
+			auto take = [&](size_t doubles) {
+				double* p = base ? reinterpret_cast<double*>(base + off) : nullptr;
+				off += (doubles * sizeof(double) + 255) / 256 * 256;
+				return p;
+			};
+			b.Ks = take(static_cast<size_t>(a.m_rows) * a.n_total);
+			b.state = take(nblk * (VG * 8 * 4 * 64));
+			b.qpart = take(static_cast<size_t>(VG) * a.m_rows);
+			b.mu_part = take(ksplit * a.m_rows);
+			b.nrm_part = take(ksplit * a.m_rows);
+			b.xs = take(xs_doubles);
+			b.counters = reinterpret_cast<int*>(take(32));
+			b.bytes = off;
+			return b;
+		}
+	} // namespace
+	bool predict_overlap_enabled()
+	{
+		static const bool on = [] {
+			const char* e = getenv("GPLE_PREDICT_OVERLAP");
+			return e != nullptr && atoi(e) != 0;
+		}();
+		return on;
+	}
+	// can this predict start beside the fit whose first early_rows rows of T are final early?  (one chunk, the full contraction on rownormp_kernel<4,4>,
+	// no derivative pass, at least two N-tiles on either side of the split)
+	bool predict_overlap_applicable(const Ctx* ctx, const PredictArgs& a, int early_rows)
+	{
+		if (!predict_overlap_enabled() || early_rows < 2 * BN || a.dv || a.mean_only || a.cut_thr > 0.0 || a.prune_thr > 0.0) return false;
+		if (a.m_rows % BM || a.n_total % BN || a.n_total / BN < 8 || a.n_total / BN > TL_MAX || early_rows / BN > a.n_total / BN - 2) return false;
+		if (static_cast<size_t>(a.m_rows) * a.n_total * sizeof(double) > PREDICT_SCRATCH_BYTES) return false; // one chunk
+		if (ctx->rownorm_pipe == 0) return false;
+		return !small_m(a) && a.m_rows / BM >= 16;
+	}
+	// the stream, events and buffers of the early work (sized for `a` and xs_doubles of test-point storage); *xs: where a caller may put the points
+	hipError_t predict_overlap_prepare(Ctx* ctx, const PredictArgs& a, size_t xs_doubles, double** xs)
+	{
+		hipError_t e;
+		if (!ctx->early_stream)
+		{
+			if ((e = hipStreamCreateWithFlags(&ctx->early_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+			for (hipEvent_t* ev : {&ctx->early_points, &ctx->early_done, &ctx->early_free})
+				if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return e;
+		}
+		const OverlapBuffers need = overlap_layout(nullptr, a, xs_doubles);
+		if (need.bytes > ctx->early_bytes)
+		{
+			if ((e = hipDeviceSynchronize()) != hipSuccess) return e; // (rare: the buffers only grow)
+			if (ctx->early_buf) (void)hipFree(ctx->early_buf);
+			ctx->early_buf = nullptr, ctx->early_bytes = 0, ctx->early_free_pending = false;
+			if ((e = hipMalloc(&ctx->early_buf, need.bytes)) != hipSuccess) return e;
+			ctx->early_bytes = need.bytes;
+		}
+		// the early stream may touch the buffers once the previous predict's main-stream part is through with them
+		if (ctx->early_free_pending && (e = hipStreamWaitEvent(ctx->early_stream, ctx->early_free, 0)) != hipSuccess) return e;
+		ctx->early_free_pending = false;
+		*xs = overlap_layout(static_cast<char*>(ctx->early_buf), a, xs_doubles).xs;
+		return hipSuccess;
+	}
+	// a.Xs must be readable on the early stream: now, or — points_ready, an event recorded on it — behind work already enqueued there; fills a.q and a.mu like launch_predict_q
+	hipError_t launch_predict_overlapped(Ctx* ctx, hipStream_t s, const PredictArgs& a, size_t xs_doubles, int early_rows, hipEvent_t t_early, hipEvent_t points_ready)
+	{
+		hipStream_t E = ctx->early_stream;
+		const OverlapBuffers b = overlap_layout(static_cast<char*>(ctx->early_buf), a, xs_doubles);
+		if (!E || b.bytes > ctx->early_bytes) return hipErrorInvalidValue;
+		static const int fit_cus = [] {
+			const char* e = getenv("GPLE_PREDICT_OVERLAP_CUS");
+			return e ? atoi(e) : 64;
+		}();
+		// GPLE_PREDICT_OVERLAP_TILES: at most that many N-tiles go early (the early part should end with the fit, not after it);
+		// GPLE_PREDICT_OVERLAP_KSTAR_LATE=1: the generation waits for the early rows too (it disturbs the factorisation's first launch otherwise)
+		static const int max_tiles = [] {
+			const char* e = getenv("GPLE_PREDICT_OVERLAP_TILES");
+			return e ? atoi(e) : 1 << 20;
+		}();
+		static const bool kstar_late = [] {
+			const char* e = getenv("GPLE_PREDICT_OVERLAP_KSTAR_LATE");
+			return e != nullptr && atoi(e) != 0;
+		}();
+		const int ksplit = gen_ksplit(a.m_rows), ntiles = a.n_total / BN, jt_split = std::max(2, std::min(early_rows / BN, max_tiles)), nblocks = a.m_rows / BM;
+		const int* none = nullptr;
+		hipError_t e;
+		// early stream: K*, store only
+		if (kstar_late && (e = hipStreamWaitEvent(E, t_early, 0)) != hipSuccess) return e;
+		hipLaunchKernelGGL((kstar_gen_kernel<0, 3>), dim3(a.m_rows / 128, ksplit), dim3(128), 0, E, a, 0, a.m_rows, b.Ks, static_cast<double*>(nullptr), static_cast<double*>(nullptr), none, none);
+		hipLaunchKernelGGL(set_int2_kernel, dim3(1), dim3(1), 0, E, b.counters, a.m_rows, 0);
+		if ((e = hipStreamWaitEvent(E, t_early, 0)) != hipSuccess) return e;
+		{
+			// the tiles below the split: one virtual group per unit (the finest units), fewer resident workgroups than CUs
+			int G = 1;
+			while (2 * G <= ROWNORM_SPLIT_MAX && 4 * (2 * G) <= 2 * ntiles) G *= 2;
+			Prune pr{b.counters + 1, b.counters, 0, nblocks, G};
+			pr.jt_lo = 0, pr.jt_hi = jt_split, pr.state = b.state, pr.state_mode = 1;
+			const int wgs = std::max(16, std::min(device_cu_count() - fit_cus, nblocks * G));
+			hipLaunchKernelGGL((rownormp_kernel<4, 4, true>), dim3(wgs), dim3(NTHREADS), 0, E, b.Ks, a.m_rows, a.T, a.ldt, a.n_total, b.qpart, static_cast<long>(a.m_rows), pr);
+		}
+		if ((e = hipEventRecord(ctx->early_done, E)) != hipSuccess) return e;
+		// main stream (behind the fit): the means, then the late tiles from the saved sums
+		if (points_ready && (e = hipStreamWaitEvent(s, points_ready, 0)) != hipSuccess) return e;
+		hipLaunchKernelGGL((kstar_gen_kernel<0, 1>), dim3(a.m_rows / 128, ksplit), dim3(128), 0, s, a, 0, a.m_rows, b.Ks, b.mu_part, b.nrm_part, none, none);
+		if ((e = hipStreamWaitEvent(s, ctx->early_done, 0)) != hipSuccess) return e;
+		{
+			Prune pr{};
+			pr.jt_lo = jt_split, pr.jt_hi = ntiles, pr.state = b.state, pr.state_mode = 2;
+			const int split = rownorm_split(a.m_rows, a.n_total);
+			chunk_timer_start(ctx);
+			ctx->last_contraction = "rownormp_kernel<4,4,false>";
+			hipLaunchKernelGGL((rownormp_kernel<4, 4, false>), dim3(nblocks, split), dim3(NTHREADS), 0, s, b.Ks, a.m_rows, a.T, a.ldt, a.n_total, b.qpart, static_cast<long>(a.m_rows), pr);
+			chunk_timer_stop(ctx);
+		}
+		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, b.qpart, a.m_rows, VG, a.q);
+		hipLaunchKernelGGL(sum_mu_kernel, dim3((a.m_rows + 255) / 256, 1), dim3(256), 0, s, b.mu_part, a.m_rows, ksplit, a.mu);
+		if ((e = hipEventRecord(ctx->early_free, s)) != hipSuccess) return e;
+		ctx->early_free_pending = true;
+		ctx->overlapped_predicts += 1;
 		return hipGetLastError();
 	}
 
