@@ -756,6 +756,21 @@ api.close()
     assert np.array_equal(res[0], res[1]), np.abs(res[0] - res[1]).max()
 
 
+@pytest.mark.parametrize("N,G,reps", [(1024, 128, 40), (256, 128, 100), (2300, 64, 20)])
+def test_repeated_predicts_agree_bit_for_bit(gpu, N, G, reps):
+    """the pipelined contraction and the fused small-n predict move their slabs by LDS-DMA into buffers that other waves are reading a step earlier or later:
+    a race would show as a run that differs from the first (probes/soak_contraction.py is the long form: 5 000 predicts at the BASELINE sizes, none differed)"""
+    from tests.test_gpu_configs import config_inputs, THETA_R
+    X, y, grid, _ = config_inputs(N, G, 5)
+    fit = gpu.real_fit(THETA_R, X, y, 0)
+    for flags in (c.PREDICT_FULL, 0):
+        first = gpu.real_predict(fit, grid, flags=flags)
+        for _ in range(reps):
+            p = gpu.real_predict(fit, grid, flags=flags)
+            assert all(np.array_equal(p[k], first[k]) for k in ("prediction", "variance", "cutoff"))
+    fit.release()
+
+
 def test_forced_128_tiles_on_odd_fork_points_stay_off_unwritten_blocks():
     """the block-row inverse runs its triangular GEMMs on sub-matrices whose origin is a fork point — a multiple of 64 only.  A
     128-tile with a triangular k-range starts at its 128-aligned diagonal tile and would take in a block above the diagonal that nobody writes
