@@ -347,6 +347,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
+    if world > torch.cuda.device_count():
+        # A rehearsal: several ranks on one GPU.  The one-launch factorisation's workgroups wait for one another inside a launch, and a neighbour process
+        # whose contraction holds every CU for seconds can starve them past their bounded wait — the library then recovers (a launch per panel) and reports
+        # the predicts enqueued before as stale (GPLE_ERR_TIMEOUT), which a multi-rank step cannot repeat without unmatching its collectives (seen once in
+        # round 4's rehearsals).  Ranks that share a GPU therefore fit with a launch per panel (no waiting kernels); ranks with a GPU each are not touched.
+        os.environ.setdefault("GPLE_CHOL_SCHEME", "step")
     torch.cuda.set_device(dev)
     # Everything (the library's kernels, torch's copies, the collectives) runs on ONE non-blocking stream, not on the legacy null stream:
     # once another library has created blocking streams in the process (RCCL does), every launch on the null stream pays for the implicit

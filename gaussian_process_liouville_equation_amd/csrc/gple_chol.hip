@@ -796,10 +796,12 @@ namespace gple
 		// spine needs next first): whatever a task waits for was drawn before it, by a workgroup that is running, so the launch makes progress with
 		// any number of its worker workgroups resident.  What the argument assumes is that workgroup 0 — the spine, which draws no ticket — is
 		// dispatched no later than the workers that wait for it; HIP dispatches the workgroups of a grid in index order, but does not promise to.
-		// The bounded wait backs that up: after a.poll_limit polls (DAG_POLL_LIMIT_DEFAULT, about 1-2 s) a wave raises the error flag, everybody
+		// The bounded wait backs that up: after a.poll_limit polls (DAG_POLL_LIMIT_DEFAULT, about 5-8 s) a wave raises the error flag, everybody
 		// leaves, and *info becomes -1; the host then repeats the factorisation with one launch per panel (no waits between workgroups:
-		// gple_capi.hip, recover_fit) — a give-up costs time, never a wrong result.
-		constexpr int DAG_POLL_LIMIT_DEFAULT = 1 << 21;
+		// gple_capi.hip, recover_fit) — a give-up costs time, never a wrong result.  (2^21 polls, 1-2 s, until round 4: two PROCESSES on one GPU, the
+		// other one's contraction holding every CU with one 110 KB workgroup each for seconds on end, starved a launch's workers past that once in a
+		// rehearsal — the first give-up seen outside the tests that force one.  A wait is better than a give-up while the other side makes progress.)
+		constexpr int DAG_POLL_LIMIT_DEFAULT = 1 << 23;
 		// the ticket floor of a launch is (epoch * DAG_MAX_LAUNCHES + launch number) << 32: a factorisation may have up to DAG_MAX_LAUNCHES launches
 		// (n = 8192: 12; more than 64, the packing of round 3, from n ~ 29k on or with GPLE_CHOL_OUTER=256 above n = 16384 — launch 64 of epoch e then
 		// had the floor of launch 0 of epoch e + 1), and epochs stay below 2^31 / DAG_MAX_LAUNCHES (dag_state)

@@ -35,7 +35,7 @@ extern "C"
 	int gple_debug_solo_allgather(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, void* hip_stream);
 	/* Test knobs of the factorisation on ONE context; a negative argument leaves its knob alone.  scheme: 0 = a launch per panel (what
 	 * GPLE_CHOL_SCHEME=step selects process-wide), 1 = one launch per outer block, 2 = back to the environment's; poll_limit: polls before a waiting
-	 * wave of the one-launch scheme gives up (0 = the default, 2^21); dag_blocks: workgroups of its launches (0 = one per CU).  giveups / recoveries
+	 * wave of the one-launch scheme gives up (0 = the default, 2^23); dag_blocks: workgroups of its launches (0 = one per CU).  giveups / recoveries
 	 * (nullable): how often the host has seen info = -1 on this context / repeated a factorisation with a launch per panel because of it. */
 	int gple_debug_chol_knobs(gple_ctx* ctx, int scheme, int poll_limit, int dag_blocks, long* giveups, long* recoveries);
 	/* Test knobs of the predict path on ONE context; 0 / 1 set a knob, 2 hands it back to the environment, a negative argument leaves it alone.
