@@ -1342,6 +1342,11 @@ namespace gple
 		int rownorm_split(int m_rows, int n_total)
 		{
 			const long blocks = m_rows / BM, ntiles = n_total / BN;
+			static const int forced = [] {
+				const char* e = getenv("GPLE_ROWNORM_SPLIT"); // A/B: groups per row block whatever the model says (must leave every group a snake pair)
+				return e ? atoi(e) : 0;
+			}();
+			if (forced > 0 && (forced == 1 || 4 * forced <= 2 * ntiles) && forced <= ROWNORM_SPLIT_MAX) return forced;
 			int best = 1;
 			double best_cost = 1e300;
 			for (int g = 1; g <= ROWNORM_SPLIT_MAX; g *= 2)
